@@ -1,0 +1,349 @@
+"""ctypes binding of libmi_pathtrace.so (the C ABI in include/mi_pathtrace.h).
+
+The host-side mirror of the reference's pathtrace surface (src/pathtrace.h:8-11):
+``Scene`` wraps the scene loader / assembler, ``Tracer`` wraps
+pathtraceInit / pathtrace / pathtraceFree.  Nothing here computes: every call
+goes through the shared library, and importing fails loudly when it is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi_pathtrace.so")
+
+PT_SPHERE, PT_CUBE, PT_GLTF_MESH = 0, 1, 2
+PT_DIFFUSE, PT_SPECULAR, PT_REFRACTIVE, PT_PBR, PT_EMITTING = 0, 1, 2, 3, 4
+PT_OPT_MATERIAL_SORT, PT_OPT_USE_BVH, PT_OPT_STAGE_TIMING, PT_OPT_COUNTERS, PT_OPT_USE_GRAPH = 1, 2, 3, 4, 5
+PT_MAX_DEPTH = 64
+
+
+class PtGeom(C.Structure):
+    _fields_ = [("type", C.c_int32), ("materialid", C.c_int32),
+                ("translation", C.c_float * 3), ("rotation", C.c_float * 3), ("scale", C.c_float * 3),
+                ("transform", C.c_float * 16), ("inverseTransform", C.c_float * 16), ("invTranspose", C.c_float * 16),
+                ("meshIndex", C.c_int32), ("triangleStart", C.c_int32), ("triangleCount", C.c_int32),
+                ("bvhIndex", C.c_int32)]
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("specularExponent", C.c_float), ("specularColor", C.c_float * 3),
+                ("transparency", C.c_float), ("roughness", C.c_float), ("metallic", C.c_float),
+                ("indexOfRefraction", C.c_float), ("emittance", C.c_float), ("type", C.c_int32),
+                ("baseColorTextureIdx", C.c_int32), ("metallicRoughnessTextureIdx", C.c_int32),
+                ("normalTextureIdx", C.c_int32), ("emissiveTextureIdx", C.c_int32), ("occlusionTextureIdx", C.c_int32),
+                ("emissiveFactor", C.c_float * 3), ("subsurfaceColor", C.c_float * 3), ("subsurfaceRadius", C.c_float),
+                ("subsurfaceRadiusRGB", C.c_float * 3), ("subsurfaceScale", C.c_float),
+                ("subsurfaceAnisotropy", C.c_float), ("subsurfaceEnabled", C.c_int32)]
+
+
+TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3),
+                      ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
+                      ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("uv2", "<f4", 2),
+                      ("materialId", "<i4")])
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("leftChild", "<i4"), ("rightChild", "<i4"),
+                       ("triangleStart", "<i4"), ("triangleCount", "<i4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("geom", "<i4"), ("triangle", "<i4"), ("materialId", "<i4"),
+                      ("normal", "<f4", 3), ("uv", "<f4", 2)])
+assert TRI_DTYPE.itemsize == 100 and NODE_DTYPE.itemsize == 40 and HIT_DTYPE.itemsize == 36
+
+
+class PtMesh(C.Structure):
+    _fields_ = [("triangles", C.c_void_p), ("triangleCount", C.c_int32),
+                ("nodes", C.c_void_p), ("nodeCount", C.c_int32),
+                ("triangleIndices", C.c_void_p), ("triangleIndexCount", C.c_int32)]
+
+
+class PtTexture(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32)]
+
+
+class PtCamera(C.Structure):
+    _fields_ = [("resolution", C.c_int32 * 2), ("position", C.c_float * 3), ("lookAt", C.c_float * 3),
+                ("view", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("fov", C.c_float * 2), ("pixelLength", C.c_float * 2)]
+
+
+class PtEnvMap(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("intensity", C.c_float), ("enabled", C.c_int32)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("geoms", C.POINTER(PtGeom)), ("geomCount", C.c_int32),
+                ("materials", C.POINTER(PtMaterial)), ("materialCount", C.c_int32),
+                ("meshes", C.POINTER(PtMesh)), ("meshCount", C.c_int32),
+                ("textures", C.POINTER(PtTexture)), ("textureCount", C.c_int32),
+                ("env", PtEnvMap), ("camera", PtCamera),
+                ("traceDepth", C.c_int32), ("iterations", C.c_int32)]
+
+
+class PtStats(C.Structure):
+    _fields_ = [("pathBounces", C.c_uint64), ("iterations", C.c_uint64),
+                ("lastLive", C.c_uint32 * PT_MAX_DEPTH), ("lastDepth", C.c_uint32),
+                ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("meshHits", C.c_uint64),
+                ("msIntersect", C.c_float), ("msSort", C.c_float), ("msShade", C.c_float),
+                ("msCompact", C.c_float), ("msCamera", C.c_float),
+                ("launchesIntersect", C.c_uint32), ("launchesShade", C.c_uint32)]
+
+
+class PtError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libmi_pathtrace.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cuda-path-tracer_amd/csrc`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.c_int, C.c_float
+    sig = {
+        "pt_create": (ip, [C.POINTER(PtSceneDesc), ip, C.POINTER(vp)]),
+        "pt_destroy": (ip, [vp]),
+        "pt_trace": (ip, [vp, ip]),
+        "pt_trace_range": (ip, [vp, ip, ip, ip]),
+        "pt_display": (ip, [vp, ip, vp]),
+        "pt_download": (ip, [vp, vp]),
+        "pt_bind_image": (ip, [vp, vp]),
+        "pt_upload_image": (ip, [vp, vp]),
+        "pt_clear": (ip, [vp]),
+        "pt_sync": (ip, [vp]),
+        "pt_set_option": (ip, [vp, ip, ip]),
+        "pt_stats": (ip, [vp, C.POINTER(PtStats)]),
+        "pt_reset_stats": (ip, [vp]),
+        "pt_stream": (vp, [vp]),
+        "pt_intersect_rays": (ip, [vp, vp, vp, ip, vp]),
+        "pt_camera_rays": (ip, [vp, ip, vp, vp]),
+        "pt_math_eval": (ip, [ip, ip, vp, vp, ip, vp]),
+        "pt_last_error": (C.c_char_p, []),
+        "pt_version": (C.c_char_p, []),
+        "pt_bvh_build": (ip, [vp, ip, ip, C.POINTER(vp)]),
+        "pt_bvh_nodes": (vp, [vp, C.POINTER(ip)]),
+        "pt_bvh_indices": (vp, [vp, C.POINTER(ip)]),
+        "pt_bvh_stats": (ip, [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]),
+        "pt_bvh_free": (None, [vp]),
+        "pt_scene_load": (ip, [C.c_char_p, C.POINTER(vp)]),
+        "pt_scene_desc": (C.POINTER(PtSceneDesc), [vp]),
+        "pt_scene_set_resolution": (ip, [vp, ip, ip]),
+        "pt_scene_set_depth": (ip, [vp, ip]),
+        "pt_scene_add_mesh": (ip, [vp, vp, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
+        "pt_scene_add_material": (ip, [vp, C.POINTER(PtMaterial)]),
+        "pt_scene_add_texture": (ip, [vp, vp, ip, ip, ip]),
+        "pt_scene_set_envmap": (ip, [vp, vp, ip, ip, fp]),
+        "pt_scene_free": (None, [vp]),
+        "pt_build_transforms": (None, [C.POINTER(fp)] * 6),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTED = _load()
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise PtError("%s failed (%d): %s" % (what, rc, lib.pt_last_error().decode()))
+    return rc
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def build_transforms(t, r, s):
+    out = [(C.c_float * 16)() for _ in range(3)]
+    lib.pt_build_transforms(_f3(t), _f3(r), _f3(s), out[0], out[1], out[2])
+    return [np.array(o, dtype=np.float32).reshape(4, 4) for o in out]   # [col][row]
+
+
+def bvh_build(tris, max_depth=24):
+    """CPU BVH build (role of BVH::build, src/bvh.cpp:30).  Returns (nodes, indices, stats)."""
+    tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+    h = C.c_void_p()
+    _check(lib.pt_bvh_build(tris.ctypes.data, len(tris), max_depth, C.byref(h)), "pt_bvh_build")
+    try:
+        n = C.c_int()
+        p = lib.pt_bvh_nodes(h, C.byref(n))
+        nodes = np.frombuffer(C.string_at(p, n.value * 40), dtype=NODE_DTYPE).copy() if n.value else np.zeros(0, NODE_DTYPE)
+        p = lib.pt_bvh_indices(h, C.byref(n))
+        idx = np.frombuffer(C.string_at(p, n.value * 4), dtype=np.int32).copy() if n.value else np.zeros(0, np.int32)
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        lib.pt_bvh_stats(h, C.byref(a), C.byref(b), C.byref(c))
+        return nodes, idx, {"nodes": a.value, "leaves": b.value, "max_depth": c.value}
+    finally:
+        lib.pt_bvh_free(h)
+
+
+class Scene:
+    """Owning scene (PtScene): JSON loader + programmatic assembly; no GPU needed."""
+
+    def __init__(self, json_path):
+        self._h = C.c_void_p()
+        _check(lib.pt_scene_load(os.fspath(json_path).encode(), C.byref(self._h)), "pt_scene_load")
+        self._keep = []
+
+    @property
+    def desc(self):
+        return lib.pt_scene_desc(self._h)
+
+    @property
+    def resolution(self):
+        d = self.desc.contents
+        return int(d.camera.resolution[0]), int(d.camera.resolution[1])
+
+    @property
+    def depth(self):
+        return int(self.desc.contents.traceDepth)
+
+    def set_resolution(self, w, h):
+        _check(lib.pt_scene_set_resolution(self._h, int(w), int(h)), "pt_scene_set_resolution")
+        return self
+
+    def set_depth(self, d):
+        _check(lib.pt_scene_set_depth(self._h, int(d)), "pt_scene_set_depth")
+        return self
+
+    def add_material(self, **kw):
+        m = PtMaterial()
+        for k in ("baseColorTextureIdx", "metallicRoughnessTextureIdx", "normalTextureIdx", "emissiveTextureIdx",
+                  "occlusionTextureIdx"):
+            setattr(m, k, -1)
+        m.indexOfRefraction = 1.0
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple, np.ndarray)):
+                setattr(m, k, _f3(v))
+            else:
+                setattr(m, k, v)
+        return _check(lib.pt_scene_add_material(self._h, C.byref(m)), "pt_scene_add_material")
+
+    def add_texture(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape[:2]
+        comps = 1 if img.ndim == 2 else img.shape[2]
+        return _check(lib.pt_scene_add_texture(self._h, img.ctypes.data, w, h, comps), "pt_scene_add_texture")
+
+    def add_mesh(self, tris, translation=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1)):
+        tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+        return _check(lib.pt_scene_add_mesh(self._h, tris.ctypes.data, len(tris), _f3(translation), _f3(rotation),
+                                            _f3(scale)), "pt_scene_add_mesh")
+
+    def set_envmap(self, rgb, intensity=1.0):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        h, w = rgb.shape[:2]
+        _check(lib.pt_scene_set_envmap(self._h, rgb.ctypes.data, w, h, float(intensity)), "pt_scene_set_envmap")
+        return self
+
+    def materials(self):
+        d = self.desc.contents
+        return [d.materials[i] for i in range(d.materialCount)]
+
+    def geoms(self):
+        d = self.desc.contents
+        return [d.geoms[i] for i in range(d.geomCount)]
+
+    def close(self):
+        if self._h:
+            lib.pt_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Tracer:
+    """pathtraceInit / pathtrace / pathtraceFree over the C ABI (one context per GPU)."""
+
+    def __init__(self, scene, device=0):
+        self._h = C.c_void_p()
+        self.scene = scene
+        desc = scene.desc if isinstance(scene, Scene) else scene
+        _check(lib.pt_create(desc, int(device), C.byref(self._h)), "pt_create")
+        d = desc.contents
+        self.width, self.height = int(d.camera.resolution[0]), int(d.camera.resolution[1])
+
+    def trace(self, it):
+        _check(lib.pt_trace(self._h, int(it)), "pt_trace")
+
+    def trace_range(self, begin, end, stride=1):
+        _check(lib.pt_trace_range(self._h, int(begin), int(end), int(stride)), "pt_trace_range")
+
+    def sync(self):
+        _check(lib.pt_sync(self._h), "pt_sync")
+
+    def clear(self):
+        _check(lib.pt_clear(self._h), "pt_clear")
+
+    def set_option(self, opt, value):
+        _check(lib.pt_set_option(self._h, int(opt), int(value)), "pt_set_option")
+
+    def bind_image(self, dev_ptr):
+        _check(lib.pt_bind_image(self._h, C.c_void_p(dev_ptr)), "pt_bind_image")
+
+    def upload_image(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        assert img.size == self.width * self.height * 3
+        _check(lib.pt_upload_image(self._h, img.ctypes.data), "pt_upload_image")
+
+    def image(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        _check(lib.pt_download(self._h, out.ctypes.data), "pt_download")
+        return out
+
+    def display(self, it, dev_rgba_ptr):
+        _check(lib.pt_display(self._h, int(it), C.c_void_p(dev_rgba_ptr)), "pt_display")
+
+    def stats(self):
+        s = PtStats()
+        _check(lib.pt_stats(self._h, C.byref(s)), "pt_stats")
+        return s
+
+    def reset_stats(self):
+        _check(lib.pt_reset_stats(self._h), "pt_reset_stats")
+
+    def stream(self):
+        return lib.pt_stream(self._h)
+
+    def intersect(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        out = np.zeros(len(o), dtype=HIT_DTYPE)
+        _check(lib.pt_intersect_rays(self._h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data), "pt_intersect_rays")
+        return out
+
+    def camera_rays(self, it):
+        n = self.width * self.height
+        o = np.empty((n, 3), np.float32)
+        d = np.empty((n, 3), np.float32)
+        _check(lib.pt_camera_rays(self._h, int(it), o.ctypes.data, d.ctypes.data), "pt_camera_rays")
+        return o, d
+
+    def close(self):
+        if self._h:
+            lib.pt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def math_eval(fn, a, b=None, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        bp = b.ctypes.data
+    _check(lib.pt_math_eval(int(device), int(fn), a.ctypes.data, bp, a.size, out.ctypes.data), "pt_math_eval")
+    return out

@@ -1,0 +1,299 @@
+/*
+ * mi_pathtrace.h — C ABI of the MI355X wavefront path tracer (libmi_pathtrace.so).
+ *
+ * Drop-in boundary for the wavefront loop of tonytgrt/CUDA-Path-Tracer.  The
+ * reference exposes four C++ functions (src/pathtrace.h:8-11):
+ *     void InitDataContainer(GuiDataContainer*);
+ *     void pathtraceInit(Scene*);
+ *     void pathtraceFree();
+ *     void pathtrace(uchar4* pbo, int frame, int iteration);
+ * operating on file-static device pointers (src/pathtrace.cu:168-201).  This
+ * header is the plain-C surface those four functions bind to: the scene is
+ * handed over as POD arrays (PtSceneDesc), state lives in an opaque context,
+ * every call returns 0 on success and a negative PT_E* code otherwise
+ * (the reference calls exit(1) in checkCUDAError, src/pathtrace.cu:27-48).
+ *
+ * All pointers inside PtSceneDesc are HOST pointers, borrowed for the
+ * duration of the call only.  Matrices are column-major (m[col*4+row]), the
+ * layout glm::mat4 uses in the reference (src/sceneStructs.h:68-70).
+ */
+#ifndef MI_PATHTRACE_H
+#define MI_PATHTRACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ enums */
+
+/* src/sceneStructs.h:16-21 */
+enum PtGeomType { PT_SPHERE = 0, PT_CUBE = 1, PT_GLTF_MESH = 2 };
+/* src/sceneStructs.h:23-30 */
+enum PtMaterialType { PT_DIFFUSE = 0, PT_SPECULAR = 1, PT_REFRACTIVE = 2, PT_PBR = 3, PT_EMITTING = 4 };
+
+enum PtError {
+    PT_OK = 0,
+    PT_EINVAL = -1,   /* bad argument / inconsistent scene description */
+    PT_EHIP = -2,     /* a HIP runtime call failed; see pt_last_error()  */
+    PT_ENOMEM = -3,
+    PT_EIO = -4,      /* scene file missing / unparsable                 */
+    PT_ELIMIT = -5    /* size beyond a documented maximum                */
+};
+
+/* ------------------------------------------------------------ scene PODs */
+
+/* src/sceneStructs.h:61-77 (Geom).  meshIndex replaces the CPU MeshData*.
+ * triangleStart / bvhIndex are filled by pt_create exactly where
+ * pathtraceInit fills them (src/pathtrace.cu:491, :308). */
+typedef struct PtGeom {
+    int32_t type;               /* PtGeomType */
+    int32_t materialid;         /* -1 for meshes (per-triangle ids)     */
+    float translation[3];
+    float rotation[3];
+    float scale[3];
+    float transform[16];
+    float inverseTransform[16];
+    float invTranspose[16];
+    int32_t meshIndex;          /* index into PtSceneDesc.meshes or -1   */
+    int32_t triangleStart;
+    int32_t triangleCount;
+    int32_t bvhIndex;
+} PtGeom;
+
+/* src/sceneStructs.h:79-111 (Material) */
+typedef struct PtMaterial {
+    float color[3];
+    float specularExponent;
+    float specularColor[3];
+    float transparency;
+    float roughness;
+    float metallic;
+    float indexOfRefraction;
+    float emittance;
+    int32_t type;               /* PtMaterialType */
+    int32_t baseColorTextureIdx;
+    int32_t metallicRoughnessTextureIdx;
+    int32_t normalTextureIdx;
+    int32_t emissiveTextureIdx;
+    int32_t occlusionTextureIdx;
+    float emissiveFactor[3];
+    float subsurfaceColor[3];
+    float subsurfaceRadius;
+    float subsurfaceRadiusRGB[3];
+    float subsurfaceScale;
+    float subsurfaceAnisotropy;
+    int32_t subsurfaceEnabled;
+} PtMaterial;
+
+/* src/sceneStructs.h:40-46 (Triangle), 100 bytes */
+typedef struct PtTriangle {
+    float v0[3], v1[3], v2[3];
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    int32_t materialId;
+} PtTriangle;
+
+/* src/bvh.h:55-65 (BVHNode), 40 bytes; leaf <=> leftChild == -1 */
+typedef struct PtBvhNode {
+    float bmin[3];
+    float bmax[3];
+    int32_t leftChild;
+    int32_t rightChild;
+    int32_t triangleStart;
+    int32_t triangleCount;
+} PtBvhNode;
+
+/* One mesh = the triangles of one glTF object (src/sceneStructs.h:48-53),
+ * optionally with a prebuilt BVH (output of pt_bvh_build).  When nodes is
+ * NULL pt_create builds the BVH itself, as initializeBVHs does
+ * (src/pathtrace.cu:269-334). */
+typedef struct PtMesh {
+    const PtTriangle* triangles;
+    int32_t triangleCount;
+    const PtBvhNode* nodes;         /* optional */
+    int32_t nodeCount;
+    const int32_t* triangleIndices; /* optional, leaf order -> triangle */
+    int32_t triangleIndexCount;
+} PtMesh;
+
+/* src/sceneStructs.h:32-38 (Texture): 8-bit, 1/3/4 interleaved components */
+typedef struct PtTexture {
+    const uint8_t* data;
+    int32_t width;
+    int32_t height;
+    int32_t components;
+} PtTexture;
+
+/* src/sceneStructs.h:119-129 (Camera) */
+typedef struct PtCamera {
+    int32_t resolution[2];
+    float position[3];
+    float lookAt[3];
+    float view[3];
+    float up[3];
+    float right[3];
+    float fov[2];
+    float pixelLength[2];
+} PtCamera;
+
+/* src/sceneStructs.h:150-157 (HostEnvironmentMap).  data = width*height RGB
+ * floats already multiplied by intensity (src/scene.cpp:810-817). */
+typedef struct PtEnvMap {
+    const float* data;
+    int32_t width;
+    int32_t height;
+    float intensity;
+    int32_t enabled;
+} PtEnvMap;
+
+typedef struct PtSceneDesc {
+    const PtGeom* geoms;         int32_t geomCount;
+    const PtMaterial* materials; int32_t materialCount;
+    const PtMesh* meshes;        int32_t meshCount;
+    const PtTexture* textures;   int32_t textureCount;
+    PtEnvMap env;
+    PtCamera camera;
+    int32_t traceDepth;          /* RenderState::traceDepth */
+    int32_t iterations;          /* RenderState::iterations (informative) */
+} PtSceneDesc;
+
+/* ------------------------------------------------------------- run-time */
+
+typedef struct PtContext PtContext;
+
+#define PT_MAX_DEPTH 64
+
+typedef struct PtStats {
+    uint64_t pathBounces;        /* sum over iterations and bounces of live paths
+                                    entering the intersect stage
+                                    (num_paths at src/pathtrace.cu:2735)          */
+    uint64_t iterations;         /* pt_trace calls since create/clear              */
+    uint32_t lastLive[PT_MAX_DEPTH]; /* live paths per bounce, last iteration      */
+    uint32_t lastDepth;          /* bounces executed in the last iteration         */
+    uint64_t nodesVisited;       /* BVH nodes box-tested  (only when counters on)  */
+    uint64_t trisTested;         /* triangle tests        (only when counters on)  */
+    uint64_t meshHits;           /* closest-hit queries that ended on a mesh       */
+    float msIntersect;           /* HIP-event time of the stages, accumulated,     */
+    float msSort;                /* only when timing is on (pt_set_option)         */
+    float msShade;
+    float msCompact;
+    float msCamera;
+    uint32_t launchesIntersect;
+    uint32_t launchesShade;
+} PtStats;
+
+/* Closest-hit record for the fixed-ray-set parity hook. */
+typedef struct PtHit {
+    float t;                     /* world distance, -1 on miss                      */
+    int32_t geom;                /* index of the hit geom, -1 on miss               */
+    int32_t triangle;            /* mesh-local triangle index, -1 for primitives    */
+    int32_t materialId;
+    float normal[3];
+    float uv[2];
+} PtHit;
+
+enum PtOption {
+    PT_OPT_MATERIAL_SORT = 1,    /* MATERIAL_SORTING, src/pathtrace.h:6 (default 1) */
+    PT_OPT_USE_BVH = 2,          /* USE_BVH, src/pathtrace.cu:193 (default 1)       */
+    PT_OPT_STAGE_TIMING = 3,     /* bracket every stage with HIP events (default 0) */
+    PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
+    PT_OPT_USE_GRAPH = 5         /* replay the iteration from a hipGraph (default 0)*/
+};
+
+/* pathtraceInit (src/pathtrace.cu:428-576): uploads the scene, builds lights,
+ * env-map CDFs and per-mesh BVHs, allocates path state for W*H paths. */
+int pt_create(const PtSceneDesc* scene, int device, PtContext** out);
+
+/* pathtraceFree (src/pathtrace.cu:578-684); NULL is a no-op. */
+int pt_destroy(PtContext* ctx);
+
+/* pathtrace(pbo = NULL, frame, iter) (src/pathtrace.cu:2659-2930): one sample
+ * per pixel, accumulated into the running-sum image.  Asynchronous on the
+ * context's stream. */
+int pt_trace(PtContext* ctx, int iter);
+
+/* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end. */
+int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
+
+/* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE
+ * buffer of W*H*4 bytes. */
+int pt_display(PtContext* ctx, int iter, uint8_t* dev_rgba);
+
+/* cudaMemcpy(hst_scene->state.image, dev_image) (src/pathtrace.cu:2916):
+ * copies the W*H*3 float running sum to host memory (synchronises). */
+int pt_download(PtContext* ctx, float* host_rgb);
+
+/* The running sum lives in caller-provided DEVICE memory (W*H*3 floats), e.g.
+ * a torch tensor that a collective reduces afterwards.  NULL = library-owned. */
+int pt_bind_image(PtContext* ctx, float* dev_rgb);
+/* Load a running sum (checkpoint/resume: the image is a plain sum). */
+int pt_upload_image(PtContext* ctx, const float* host_rgb);
+int pt_clear(PtContext* ctx);
+int pt_sync(PtContext* ctx);
+int pt_set_option(PtContext* ctx, int option, int value);
+int pt_stats(PtContext* ctx, PtStats* out);
+int pt_reset_stats(PtContext* ctx);
+/* The HIP stream the context launches on (hipStream_t as void*). */
+void* pt_stream(PtContext* ctx);
+
+/* Parity hook: closest hit of n world-space rays (host arrays of xyz triples)
+ * against the uploaded scene, through the same device code the intersect
+ * stage runs (computeIntersectionsBVH, src/pathtrace.cu:834-934). */
+int pt_intersect_rays(PtContext* ctx, const float* origins, const float* directions,
+                      int n, PtHit* out);
+
+/* Parity hook: the camera stage alone (generateRayFromCamera,
+ * src/pathtrace.cu:694-745): W*H origins and directions to host arrays. */
+int pt_camera_rays(PtContext* ctx, int iter, float* origins, float* directions);
+
+/* Device-side self check of the arithmetic the kernels rely on (IEEE div/sqrt,
+ * the library's sin/cos/acos/atan2/exp/log): evaluates fn on n host inputs
+ * (b may be NULL for unary functions) and returns the raw float results. */
+int pt_math_eval(int device, int fn, const float* a, const float* b, int n, float* out);
+
+const char* pt_last_error(void);
+const char* pt_version(void);
+
+/* ------------------------------------------------- host-side scene helpers */
+
+/* CPU BVH builder (role of BVH::build, src/bvh.cpp:30-238): SAH with 11
+ * sampled planes per axis above 32 triangles, median split below, leaves of
+ * <= 4 triangles, depth cap maxDepth.  No GPU needed. */
+typedef struct PtBvh PtBvh;
+int pt_bvh_build(const PtTriangle* tris, int n, int maxDepth, PtBvh** out);
+const PtBvhNode* pt_bvh_nodes(const PtBvh* b, int* count);
+const int32_t* pt_bvh_indices(const PtBvh* b, int* count);
+int pt_bvh_stats(const PtBvh* b, int* nodeCount, int* leafCount, int* maxDepth);
+void pt_bvh_free(PtBvh* b);
+
+/* Scene loader (role of Scene::loadFromJSON, src/scene.cpp:570-919, and of
+ * the camera set-up in main.cpp:750-769, :788-807).  Returns an owning scene
+ * whose PtSceneDesc stays valid until pt_scene_free.  No GPU needed. */
+typedef struct PtScene PtScene;
+int pt_scene_load(const char* json_path, PtScene** out);
+const PtSceneDesc* pt_scene_desc(const PtScene* s);
+/* Override RES / DEPTH (all shipped scenes are 1200x1200). */
+int pt_scene_set_resolution(PtScene* s, int width, int height);
+int pt_scene_set_depth(PtScene* s, int depth);
+/* Append a triangle mesh object (triangles already carry the object's TRS
+ * baked in, as loadGLTFModel does, src/scene.cpp:265,423-425) together with
+ * its materials and textures; TRS is kept as the geom transform as well
+ * (src/scene.cpp:848-851). */
+int pt_scene_add_mesh(PtScene* s, const PtTriangle* tris, int n,
+                      const float translation[3], const float rotation[3], const float scale[3]);
+int pt_scene_add_material(PtScene* s, const PtMaterial* m);
+int pt_scene_add_texture(PtScene* s, const uint8_t* data, int w, int h, int comps);
+int pt_scene_set_envmap(PtScene* s, const float* rgb, int w, int h, float intensity);
+void pt_scene_free(PtScene* s);
+
+/* utilityCore::buildTransformationMatrix + glm::inverse + glm::inverseTranspose
+ * (src/utilities.cpp:85-93, src/scene.cpp:848-851) for one TRS triple. */
+void pt_build_transforms(const float translation[3], const float rotation[3], const float scale[3],
+                         float transform[16], float inverse[16], float invTranspose[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_PATHTRACE_H */

@@ -1,0 +1,1635 @@
+/*
+ * pt_oracle.cpp — TEST INFRASTRUCTURE, never linked into the shipped library.
+ *
+ * CPU restatement of the wavefront path-tracing loop of
+ * tonytgrt/CUDA-Path-Tracer.  Every function cites the reference lines it
+ * follows.  Vector arithmetic reproduces GLM 0.9.6.3's operation order
+ * (external/include/glm/detail/func_geometric.inl, type_mat4x4.inl:592-628,
+ * func_common.inl:409-472) because results are compared bit for bit.
+ *
+ * PARITY PINS: the reference ships no tests or golden vectors for this path
+ * and cannot be built in this image (it needs the CUDA toolkit headers), so
+ * the oracle is pinned by the known-answer values that were recorded from a
+ * host run of the reference's own kernels (tests/golden/reference_kats.json):
+ * RNG stream, hemisphere sample, unit-sphere hit, camera ray, the live-path
+ * curve / path-bounce total / mean radiance of cornell.json at 800x800.
+ * Anything those values do not exercise is "parity unpinned".
+ *
+ * Build with -ffp-contract=off (no FMA contraction).
+ */
+#include "pt_oracle.h"
+#include "det_math.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+/* ------------------------------------------------------------------------
+ * arithmetic mode (see det_math.h)
+ * ---------------------------------------------------------------------- */
+struct MathFns {
+    float (*sin)(float);
+    float (*cos)(float);
+    float (*acos)(float);
+    float (*atan2)(float, float);
+    float (*exp)(float);
+    float (*log)(float);
+    float (*pow5)(float);
+};
+float libm_pow5(float x) { return powf(x, 5.0f); }
+const MathFns kLibm = { sinf, cosf, acosf, atan2f, expf, logf, libm_pow5 };
+const MathFns kDet = { detm::sinf_det, detm::cosf_det, detm::acosf_det, detm::atan2f_det,
+                       detm::expf_det, detm::logf_det, detm::pow5_det };
+
+const float PI = 3.1415926535897932384626422832795028841971f;      /* src/utilities.h:13 */
+const float TWO_PI = 6.2831853071795864769252867665590057683943f;  /* src/utilities.h:14 */
+const float SQRT_OF_ONE_THIRD = 0.5773502691896257645091487805019574556476f;
+
+/* CUDA fminf/fmaxf: a NaN operand loses */
+inline float fmin_(float a, float b) { return (b != b) ? a : ((a != a) ? b : (a < b ? a : b)); }
+inline float fmax_(float a, float b) { return (b != b) ? a : ((a != a) ? b : (a > b ? a : b)); }
+/* glm::min / glm::max, func_common.inl:409-435 */
+inline float gmin(float x, float y) { return x < y ? x : y; }
+inline float gmax(float x, float y) { return x > y ? x : y; }
+inline float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+
+/* ------------------------------------------------------------------------
+ * vectors, GLM operation order
+ * ---------------------------------------------------------------------- */
+struct V2 { float x, y; };
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    explicit V3(float s) : x(s), y(s), z(s) {}
+    explicit V3(const float* p) : x(p[0]), y(p[1]), z(p[2]) {}
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    float& at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+struct V4 { float x, y, z, w; };
+
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator*(V3 a, V3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator/(V3 a, V3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline V3 operator*(V3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return V3(s * a.x, s * a.y, s * a.z); }
+inline V3 operator/(V3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+inline V3 operator/(float s, V3 a) { return V3(s / a.x, s / a.y, s / a.z); }
+inline V3 operator+(V3 a, float s) { return V3(a.x + s, a.y + s, a.z + s); }
+inline V3 operator+(float s, V3 a) { return V3(s + a.x, s + a.y, s + a.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3& operator*=(V3& a, V3 b) { a = a * b; return a; }
+inline V3& operator*=(V3& a, float s) { a = a * s; return a; }
+inline V3& operator/=(V3& a, float s) { a = a / s; return a; }
+inline V3& operator+=(V3& a, V3 b) { a = a + b; return a; }
+inline V2 operator*(float s, V2 a) { return V2{ s * a.x, s * a.y }; }
+inline V2 operator+(V2 a, V2 b) { return V2{ a.x + b.x, a.y + b.y }; }
+inline V4 operator*(V4 a, float s) { return V4{ a.x * s, a.y * s, a.z * s, a.w * s }; }
+inline V4 operator+(V4 a, V4 b) { return V4{ a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w }; }
+
+/* func_geometric.inl:65-72 */
+inline float dot(V3 a, V3 b) { V3 t = a * b; return t.x + t.y + t.z; }
+/* func_geometric.inl:133-142 */
+inline V3 cross(V3 x, V3 y)
+{
+    return V3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+/* func_geometric.inl:94-100 */
+inline float length(V3 v) { return sqrtf(dot(v, v)); }
+/* func_geometric.inl:153-159 with func_exponential.inl:148-153: x * (1/sqrt(dot)) */
+inline V3 normalize(V3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+/* func_geometric.inl:175-180 */
+inline V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0f; }
+/* func_common.inl:96-105: x + a*(y-x) */
+inline V3 mix(V3 x, V3 y, float a) { return x + a * (y - x); }
+inline V3 vmin(V3 a, V3 b) { return V3(gmin(a.x, b.x), gmin(a.y, b.y), gmin(a.z, b.z)); }
+inline V3 vmax(V3 a, V3 b) { return V3(gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)); }
+inline V3 vclamp(V3 v, V3 lo, V3 hi) { return vmin(vmax(v, lo), hi); }
+
+/* column-major 4x4; type_mat4x4.inl:592-628: (m0*x + m1*y) + (m2*z + m3*w) */
+struct M4 { float c[4][4]; };
+inline V3 mulMV(const M4& m, V3 v, float w)
+{
+    float r[3];
+    for (int i = 0; i < 3; ++i) {
+        float mul0 = m.c[0][i] * v.x;
+        float mul1 = m.c[1][i] * v.y;
+        float add0 = mul0 + mul1;
+        float mul2 = m.c[2][i] * v.z;
+        float mul3 = m.c[3][i] * w;
+        float add1 = mul2 + mul3;
+        r[i] = add0 + add1;
+    }
+    return V3(r[0], r[1], r[2]);
+}
+inline M4 loadM4(const float* p) { M4 m; memcpy(m.c, p, 64); return m; }
+
+/* ------------------------------------------------------------------------
+ * RNG: thrust::default_random_engine (minstd_rand) + uniform_real_distribution
+ * as rocThrust/thrust implement them (thrust/random/detail/
+ * linear_congruential_engine.inl seed()/operator(),
+ * uniform_real_distribution.inl:71-79); hash: src/intersections.h:13-22;
+ * seeding: src/pathtrace.cu:138-143.
+ * ---------------------------------------------------------------------- */
+inline unsigned utilhash(unsigned a)
+{
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+struct Rng {
+    uint32_t x;
+    Rng(int iter, int index, int depth)
+    {
+        unsigned h = utilhash((unsigned)((1u << 31) | ((unsigned)depth << 22) | (unsigned)iter)) ^ utilhash((unsigned)index);
+        x = h % 2147483647u;
+        if (x == 0) x = 1;
+    }
+    float u01()
+    {
+        x = (uint32_t)(((uint64_t)x * 48271ull) % 2147483647ull);
+        float r = (float)(x - 1u);
+        r /= (1.0f + (float)2147483645u);
+        return (r * (1.0f - 0.0f)) + 0.0f;
+    }
+};
+
+/* ------------------------------------------------------------------------
+ * scene
+ * ---------------------------------------------------------------------- */
+struct Geom {
+    int type, materialid;
+    V3 translation, rotation, scale;
+    M4 transform, inverseTransform, invTranspose;
+    int meshIndex, triangleStart, triangleCount, bvhIndex;
+};
+struct Mesh {
+    std::vector<PtTriangle> tris;
+    std::vector<PtBvhNode> nodes;
+    std::vector<int32_t> indices;
+};
+struct Light { int geomIdx; float area; float pdf; };
+struct Tex { std::vector<uint8_t> data; int width, height, components; };
+struct Env {
+    bool enabled = false;
+    int width = 0, height = 0;
+    float intensity = 1.0f;
+    std::vector<V3> data;
+    std::vector<float> marginalCDF, conditionalCDFs;
+    float totalPower = 0.0f;
+    bool hasData() const { return !data.empty(); }
+    bool hasCdf() const { return !marginalCDF.empty() && !conditionalCDFs.empty(); }
+};
+struct Ray { V3 origin, direction; };
+struct PathSegment {
+    Ray ray; V3 color; int pixelIndex; int remainingBounces; bool prevIsSpecular;
+};
+struct Isect { float t; V3 normal; int materialId; V2 uv; int geom; int tri; };
+
+struct Counters { uint64_t nodes = 0, tris = 0, meshHits = 0; };
+
+} // namespace
+
+struct Oracle {
+    std::vector<Geom> geoms;
+    std::vector<PtMaterial> materials;
+    std::vector<Mesh> meshes;
+    std::vector<PtTriangle> triangles;     /* all meshes concatenated, src/pathtrace.cu:483-505 */
+    std::vector<Tex> textures;
+    std::vector<Light> lights;
+    Env env;
+    PtCamera cam;
+    int traceDepth = 8;
+    bool anyBvh = false;
+    /* options */
+    bool sortByMaterial = true, useBvh = true, counters = false;
+    const MathFns* M = &kLibm;
+    /* state */
+    std::vector<V3> image;
+    std::vector<PathSegment> paths, pathsSorted;
+    std::vector<Isect> isects, isectsSorted;
+    std::vector<int> keys, order;
+    PtStats stats;
+    Counters cnt;
+};
+
+namespace {
+
+/* ------------------------------------------------------------------------
+ * primitives — src/intersections.cu
+ * ---------------------------------------------------------------------- */
+
+/* src/intersections.h:29-32 */
+inline V3 getPointOnRay(const Ray& r, float t) { return r.origin + (t - .0001f) * normalize(r.direction); }
+
+/* src/intersections.cu:4-58 */
+float boxIntersectionTest(const Geom& box, const Ray& r, V3& P, V3& N, bool& outside)
+{
+    Ray q;
+    q.origin = mulMV(box.inverseTransform, r.origin, 1.0f);
+    q.direction = normalize(mulMV(box.inverseTransform, r.direction, 0.0f));
+
+    float tmin = -1e38f, tmax = 1e38f;
+    V3 tmin_n, tmax_n;
+    for (int xyz = 0; xyz < 3; ++xyz) {
+        float qd = q.direction[xyz];
+        float t1 = (-0.5f - q.origin[xyz]) / qd;
+        float t2 = (+0.5f - q.origin[xyz]) / qd;
+        float ta = gmin(t1, t2);
+        float tb = gmax(t1, t2);
+        V3 n;
+        n.at(xyz) = t2 < t1 ? +1.0f : -1.0f;
+        if (ta > 0 && ta > tmin) { tmin = ta; tmin_n = n; }
+        if (tb < tmax) { tmax = tb; tmax_n = n; }
+    }
+    if (tmax >= tmin && tmax > 0) {
+        outside = true;
+        if (tmin <= 0) { tmin = tmax; tmin_n = tmax_n; outside = false; }
+        P = mulMV(box.transform, getPointOnRay(q, tmin), 1.0f);
+        N = normalize(mulMV(box.invTranspose, tmin_n, 0.0f));
+        return length(r.origin - P);
+    }
+    return -1;
+}
+
+/* src/intersections.cu:60-114 */
+float sphereIntersectionTest(const Geom& sphere, const Ray& r, V3& P, V3& N, bool& outside)
+{
+    V3 ro = mulMV(sphere.inverseTransform, r.origin, 1.0f);
+    V3 rd = normalize(mulMV(sphere.inverseTransform, r.direction, 0.0f));
+    Ray rt{ ro, rd };
+
+    float vDotDirection = dot(rt.origin, rt.direction);
+    float radicand = vDotDirection * vDotDirection - (dot(rt.origin, rt.origin) - 0.25f /* powf(.5,2) */);
+    if (radicand < 0) return -1;
+
+    float squareRoot = sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+
+    float t = 0;
+    if (t1 < 0 && t2 < 0) return -1;
+    else if (t1 > 0 && t2 > 0) { t = fmin_(t1, t2); outside = true; }
+    else { t = fmax_(t1, t2); outside = false; }
+
+    V3 objP = getPointOnRay(rt, t);
+    P = mulMV(sphere.transform, objP, 1.0f);
+    N = normalize(mulMV(sphere.invTranspose, objP, 0.0f));
+    if (!outside) N = -N;
+    return length(r.origin - P);
+}
+
+/* Moller-Trumbore, src/intersections.cu:116-166 and :268-308 (same arithmetic) */
+inline float triangleTest(const PtTriangle& tri, const Ray& ray, V3& bary)
+{
+    const float EPS = 0.0000001f;
+    V3 v0(tri.v0), v1(tri.v1), v2(tri.v2);
+    V3 edge1 = v1 - v0;
+    V3 edge2 = v2 - v0;
+    V3 h = cross(ray.direction, edge2);
+    float a = dot(edge1, h);
+    if (a > -EPS && a < EPS) return -1.0f;
+    float f = 1.0f / a;
+    V3 s = ray.origin - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    V3 q = cross(s, edge1);
+    float v = f * dot(ray.direction, q);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    float t = f * dot(edge2, q);
+    if (t > EPS) {
+        float w = 1.0f - u - v;
+        bary = V3(w, u, v);
+        return t;
+    }
+    return -1.0f;
+}
+
+/* src/intersections.cu:248-265 */
+inline bool intersectAABB(const Ray& ray, const float* bmin, const float* bmax, float& tMin, float& tMax)
+{
+    V3 invDir = 1.0f / ray.direction;
+    V3 t0 = (V3(bmin) - ray.origin) * invDir;
+    V3 t1 = (V3(bmax) - ray.origin) * invDir;
+    V3 tmin = vmin(t0, t1);
+    V3 tmax = vmax(t0, t1);
+    tMin = gmax(gmax(tmin.x, tmin.y), tmin.z);
+    tMax = gmin(gmin(tmax.x, tmax.y), tmax.z);
+    return tMax >= tMin && tMax >= 0.0f;
+}
+
+/* hit epilogue shared by both mesh paths: src/intersections.cu:215-244, :388-419 */
+inline float meshEpilogue(const Geom& mesh, const PtTriangle& hitTri, V3 bary, V3 localP, const Ray& r,
+                          V3& P, V3& N, bool& outside, V2& uv, int& materialId)
+{
+    V3 localNormal = normalize(bary.x * V3(hitTri.n0) + bary.y * V3(hitTri.n1) + bary.z * V3(hitTri.n2));
+    V2 uv0{ hitTri.uv0[0], hitTri.uv0[1] }, uv1{ hitTri.uv1[0], hitTri.uv1[1] }, uv2{ hitTri.uv2[0], hitTri.uv2[1] };
+    uv = bary.x * uv0 + bary.y * uv1 + bary.z * uv2;
+    materialId = hitTri.materialId;
+    P = mulMV(mesh.transform, localP, 1.0f);
+    N = normalize(mulMV(mesh.invTranspose, localNormal, 0.0f));
+    outside = dot(r.direction, N) < 0.0f;
+    if (!outside) N = -N;
+    return length(r.origin - P);
+}
+
+/* linear scan: src/intersections.cu:168-245 (and the fallback at :423-484) */
+float meshIntersectionLinear(const Oracle& S, const Geom& mesh, const Ray& r, V3& P, V3& N, bool& outside,
+                             V2& uv, int& materialId, int& triOut, Counters& cnt)
+{
+    Ray lr;
+    lr.origin = mulMV(mesh.inverseTransform, r.origin, 1.0f);
+    lr.direction = normalize(mulMV(mesh.inverseTransform, r.direction, 0.0f));
+    float t_min = FLT_MAX;
+    V3 bestBary, bestP;
+    int best = -1;
+    for (int i = 0; i < mesh.triangleCount; i++) {
+        int triIdx = mesh.triangleStart + i;
+        V3 bary;
+        float t = triangleTest(S.triangles[triIdx], lr, bary);
+        cnt.tris++;
+        if (t > 0.0f && t < t_min) {
+            t_min = t; bestBary = bary; best = triIdx;
+            bestP = lr.origin + lr.direction * t;   /* intersect, :160 */
+        }
+    }
+    if (best < 0) return -1.0f;
+    triOut = best - mesh.triangleStart;
+    cnt.meshHits++;
+    return meshEpilogue(mesh, S.triangles[best], bestBary, bestP, r, P, N, outside, uv, materialId);
+}
+
+/* stack traversal: src/intersections.cu:311-421.  Push left then right, so the
+ * right child is popped first; strict '<' keeps the first of equal hits;
+ * pushes beyond 64 entries are dropped (src/bvh.h:12). */
+float meshIntersectionBVH(const Oracle& S, const Geom& mesh, const Mesh& M, const Ray& r, V3& P, V3& N,
+                          bool& outside, V2& uv, int& materialId, int& triOut, Counters& cnt)
+{
+    Ray lr;
+    lr.origin = mulMV(mesh.inverseTransform, r.origin, 1.0f);
+    lr.direction = normalize(mulMV(mesh.inverseTransform, r.direction, 0.0f));
+
+    int stack[64];
+    int sp = 0;
+    stack[sp++] = 0;
+    float closestT = FLT_MAX;
+    bool hitFound = false;
+    V3 bestBary;
+    int bestTri = -1;
+    const PtTriangle* meshTris = S.triangles.data() + mesh.triangleStart;
+
+    while (sp > 0) {
+        int nodeIdx = stack[--sp];
+        const PtBvhNode& node = M.nodes[nodeIdx];
+        float tMin, tMax;
+        cnt.nodes++;
+        if (!intersectAABB(lr, node.bmin, node.bmax, tMin, tMax)) continue;
+        if (tMin > closestT) continue;
+        if (node.leftChild == -1) {
+            for (int i = 0; i < node.triangleCount; i++) {
+                int triIdx = M.indices[node.triangleStart + i];
+                V3 bary;
+                float triT = triangleTest(meshTris[triIdx], lr, bary);
+                cnt.tris++;
+                if (triT > 0.0f && triT < closestT) {
+                    closestT = triT; bestBary = bary; bestTri = triIdx; hitFound = true;
+                }
+            }
+        } else {
+            if (node.leftChild >= 0 && sp < 64) stack[sp++] = node.leftChild;
+            if (node.rightChild >= 0 && sp < 64) stack[sp++] = node.rightChild;
+        }
+    }
+    if (!hitFound) return -1.0f;
+    triOut = bestTri;
+    cnt.meshHits++;
+    V3 localP = lr.origin + lr.direction * closestT;
+    return meshEpilogue(mesh, meshTris[bestTri], bestBary, localP, r, P, N, outside, uv, materialId);
+}
+
+inline float meshIntersect(const Oracle& S, const Geom& g, const Ray& r, V3& P, V3& N, bool& outside,
+                           V2& uv, int& materialId, int& tri, Counters& cnt, bool forceLinear)
+{
+    /* src/pathtrace.cu:887-905: BVH when enabled and present, else linear */
+    if (!forceLinear && S.useBvh && g.bvhIndex >= 0 && !S.meshes[g.meshIndex].nodes.empty())
+        return meshIntersectionBVH(S, g, S.meshes[g.meshIndex], r, P, N, outside, uv, materialId, tri, cnt);
+    return meshIntersectionLinear(S, g, r, P, N, outside, uv, materialId, tri, cnt);
+}
+
+/* closest hit over all geoms: src/pathtrace.cu:751-832 / :834-934 */
+void closestHit(const Oracle& S, const Ray& ray, Isect& out, Counters& cnt, bool forceLinear)
+{
+    float t = -1.0f;
+    float t_min = FLT_MAX;
+    int hit_geom = -1, hit_mat = -1, hit_tri = -1;
+    V3 normal;
+    V2 hit_uv{ 0.0f, 0.0f };
+    for (int i = 0; i < (int)S.geoms.size(); i++) {
+        const Geom& g = S.geoms[i];
+        V3 tmpP, tmpN; bool tmpOut = true; V2 tmpUv{ 0.5f, 0.5f }; int tmpMat = -1, tmpTri = -1;
+        if (g.type == PT_CUBE) {
+            t = boxIntersectionTest(g, ray, tmpP, tmpN, tmpOut);
+            tmpMat = g.materialid;
+        } else if (g.type == PT_SPHERE) {
+            t = sphereIntersectionTest(g, ray, tmpP, tmpN, tmpOut);
+            tmpMat = g.materialid;
+        } else if (g.type == PT_GLTF_MESH) {
+            t = meshIntersect(S, g, ray, tmpP, tmpN, tmpOut, tmpUv, tmpMat, tmpTri, cnt, forceLinear);
+        }
+        if (t > 0.0f && t_min > t) {
+            t_min = t; hit_geom = i; normal = tmpN; hit_mat = tmpMat; hit_uv = tmpUv; hit_tri = tmpTri;
+        }
+    }
+    if (hit_geom == -1) {
+        /* the record was memset to 0 (src/pathtrace.cu:2732); only t is written (:923) */
+        out.t = -1.0f; out.normal = V3(); out.materialId = 0; out.uv = V2{ 0, 0 }; out.geom = -1; out.tri = -1;
+    } else {
+        out.t = t_min; out.materialId = hit_mat; out.normal = normal; out.uv = hit_uv;
+        out.geom = hit_geom; out.tri = hit_tri;
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * sampling helpers
+ * ---------------------------------------------------------------------- */
+
+/* src/interactions.cu:7-45 */
+V3 hemisphereCosine(const MathFns& M, V3 normal, Rng& rng)
+{
+    float up = sqrtf(rng.u01());
+    float over = sqrtf(1 - up * up);
+    float around = rng.u01() * TWO_PI;
+    V3 notNormal;
+    if (fabsf(normal.x) < SQRT_OF_ONE_THIRD) notNormal = V3(1, 0, 0);
+    else if (fabsf(normal.y) < SQRT_OF_ONE_THIRD) notNormal = V3(0, 1, 0);
+    else notNormal = V3(0, 0, 1);
+    V3 perp1 = normalize(cross(normal, notNormal));
+    V3 perp2 = normalize(cross(normal, perp1));
+    return up * normal + M.cos(around) * over * perp1 + M.sin(around) * over * perp2;
+}
+
+/* src/pathtrace.cu:937-961 */
+V4 texel(const Tex& tex, int x, int y)
+{
+    int idx = (y * tex.width + x) * tex.components;
+    const uint8_t* d = tex.data.data();
+    if (tex.components == 3) return V4{ d[idx] / 255.0f, d[idx + 1] / 255.0f, d[idx + 2] / 255.0f, 1.0f };
+    if (tex.components == 4) return V4{ d[idx] / 255.0f, d[idx + 1] / 255.0f, d[idx + 2] / 255.0f, d[idx + 3] / 255.0f };
+    if (tex.components == 1) { float v = d[idx] / 255.0f; return V4{ v, v, v, 1.0f }; }
+    return V4{ 1.0f, 0.0f, 1.0f, 1.0f };
+}
+/* src/pathtrace.cu:989-1019 */
+V4 sampleTexture(const Tex& tex, V2 uv)
+{
+    uv.x = uv.x - floorf(uv.x);
+    uv.y = uv.y - floorf(uv.y);
+    float fx = uv.x * (tex.width - 1);
+    float fy = uv.y * (tex.height - 1);
+    int x0 = (int)floorf(fx);
+    int y0 = (int)floorf(fy);
+    int x1 = std::min(x0 + 1, tex.width - 1);
+    int y1 = std::min(y0 + 1, tex.height - 1);
+    float wx = fx - x0;
+    float wy = fy - y0;
+    V4 p00 = texel(tex, x0, y0), p10 = texel(tex, x1, y0), p01 = texel(tex, x0, y1), p11 = texel(tex, x1, y1);
+    V4 p0 = p00 * (1.0f - wx) + p10 * wx;
+    V4 p1 = p01 * (1.0f - wx) + p11 * wx;
+    return p0 * (1.0f - wy) + p1 * wy;
+}
+
+/* src/pathtrace.cu:1030-1075 */
+V3 sampleEnvironmentMap(const MathFns& M, V3 direction, const Env& env)
+{
+    if (!env.enabled || !env.hasData()) return V3(0.0f);
+    float theta = M.acos(fmax_(-1.0f, fmin_(1.0f, direction.y)));
+    float phi = M.atan2(direction.z, direction.x);
+    float u = (phi + PI) / (2.0f * PI);
+    float v = theta / PI;
+    u = fmax_(0.0f, fmin_(1.0f, u));
+    v = fmax_(0.0f, fmin_(1.0f, v));
+    float fx = u * (env.width - 1);
+    float fy = v * (env.height - 1);
+    int x0 = (int)floorf(fx);
+    int y0 = (int)floorf(fy);
+    int x1 = std::min(x0 + 1, env.width - 1);
+    int y1 = std::min(y0 + 1, env.height - 1);
+    float wx = fx - x0;
+    float wy = fy - y0;
+    V3 p00 = env.data[y0 * env.width + x0], p10 = env.data[y0 * env.width + x1];
+    V3 p01 = env.data[y1 * env.width + x0], p11 = env.data[y1 * env.width + x1];
+    V3 p0 = p00 * (1.0f - wx) + p10 * wx;
+    V3 p1 = p01 * (1.0f - wx) + p11 * wx;
+    return p0 * (1.0f - wy) + p1 * wy;
+}
+
+/* src/pathtrace.cu:1091-1144 */
+V3 sampleLight(const MathFns& M, const Geom& g, Rng& rng)
+{
+    if (g.type == PT_SPHERE) {
+        float u = rng.u01();
+        float v = rng.u01();
+        float theta = 2.0f * PI * u;
+        float phi = M.acos(1.0f - 2.0f * v);
+        float radius = g.scale.x * 0.5f;
+        V3 local(radius * M.sin(phi) * M.cos(theta), radius * M.sin(phi) * M.sin(theta), radius * M.cos(phi));
+        return mulMV(g.transform, local, 1.0f);
+    }
+    if (g.type == PT_CUBE) {
+        float faceChoice = rng.u01() * 6.0f;
+        int face = (int)faceChoice;
+        float u = rng.u01() - 0.5f;
+        float v = rng.u01() - 0.5f;
+        V3 local;
+        switch (face) {
+        case 0: local = V3(0.5f, u, v); break;
+        case 1: local = V3(-0.5f, u, v); break;
+        case 2: local = V3(u, 0.5f, v); break;
+        case 3: local = V3(u, -0.5f, v); break;
+        case 4: local = V3(u, v, 0.5f); break;
+        default: local = V3(u, v, -0.5f); break;
+        }
+        return mulMV(g.transform, local, 1.0f);
+    }
+    return g.translation;
+}
+
+/* src/pathtrace.cu:1339-1354 */
+int binarySearch(const float* cdf, int size, float value)
+{
+    int left = 0, right = size - 1;
+    while (left < right) {
+        int mid = (left + right) / 2;
+        if (cdf[mid] < value) left = mid + 1; else right = mid;
+    }
+    return left;
+}
+
+/* src/pathtrace.cu:1412-1472 */
+V3 sampleEnvImportance(const MathFns& M, const Env& env, Rng& rng, V3& outDir, float& outPdf)
+{
+    if (!env.hasCdf()) {
+        outDir = hemisphereCosine(M, V3(0, 1, 0), rng);
+        outPdf = 1.0f / (2.0f * PI);
+        return sampleEnvironmentMap(M, outDir, env);
+    }
+    float u = rng.u01();
+    float v = rng.u01();
+    int y = binarySearch(env.marginalCDF.data(), env.height, v);
+    y = std::min(y, env.height - 1);
+    const float* rowCDF = env.conditionalCDFs.data() + (size_t)y * env.width;
+    int x = binarySearch(rowCDF, env.width, u);
+    x = std::min(x, env.width - 1);
+    float phi = (x + 0.5f) * 2.0f * PI / env.width - PI;
+    float theta = (y + 0.5f) * PI / env.height;
+    float sinTheta = M.sin(theta);
+    float cosTheta = M.cos(theta);
+    outDir = normalize(V3(sinTheta * M.cos(phi), cosTheta, sinTheta * M.sin(phi)));
+    V3 color = env.data[(size_t)y * env.width + x];
+    float luminance = 0.299f * color.x + 0.587f * color.y + 0.114f * color.z;
+    float pdfImage = luminance * sinTheta;
+    if (env.totalPower > 0) pdfImage /= env.totalPower;
+    float pixelArea = (2.0f * PI / env.width) * (PI / env.height);
+    outPdf = pdfImage / (pixelArea * sinTheta);
+    outPdf = fmax_(outPdf, 1e-6f);
+    return color;
+}
+
+/* src/pathtrace.cu:1474-1511 */
+float envPdfImportance(const MathFns& M, V3 direction, const Env& env)
+{
+    if (!env.hasCdf()) return 1.0f / (2.0f * PI);
+    float theta = M.acos(fmax_(-1.0f, fmin_(1.0f, direction.y)));
+    float phi = M.atan2(direction.z, direction.x);
+    float u = (phi + PI) / (2.0f * PI);
+    float v = theta / PI;
+    int x = std::min((int)(u * env.width), env.width - 1);
+    int y = std::min((int)(v * env.height), env.height - 1);
+    V3 color = env.data[(size_t)y * env.width + x];
+    float luminance = 0.299f * color.x + 0.587f * color.y + 0.114f * color.z;
+    float sinTheta = M.sin(theta);
+    float pdfImage = luminance * sinTheta;
+    if (env.totalPower > 0) pdfImage /= env.totalPower;
+    float pixelArea = (2.0f * PI / env.width) * (PI / env.height);
+    float pdf = pdfImage / (pixelArea * sinTheta);
+    return fmax_(pdf, 1e-6f);
+}
+
+/* shadow test towards a light: src/pathtrace.cu:1861-1895, :2171-2226 */
+bool lightVisible(const Oracle& S, const Ray& shadowRay, int lightGeom, float dist, Counters& cnt)
+{
+    for (int gi = 0; gi < (int)S.geoms.size(); gi++) {
+        if (gi == lightGeom) continue;
+        const Geom& occ = S.geoms[gi];
+        V3 p, n; bool o; float t = -1.0f;
+        if (occ.type == PT_SPHERE) t = sphereIntersectionTest(occ, shadowRay, p, n, o);
+        else if (occ.type == PT_CUBE) t = boxIntersectionTest(occ, shadowRay, p, n, o);
+        else if (occ.type == PT_GLTF_MESH) { V2 uv; int m, tri; t = meshIntersect(S, occ, shadowRay, p, n, o, uv, m, tri, cnt, false); }
+        if (t > 0.001f && t < dist - 0.001f) return false;
+    }
+    return true;
+}
+/* shadow test towards the environment: src/pathtrace.cu:1969-1993, :2270-2294 */
+bool envVisible(const Oracle& S, const Ray& shadowRay, Counters& cnt)
+{
+    bool visible = true;
+    for (int i = 0; i < (int)S.geoms.size() && visible; i++) {
+        const Geom& g = S.geoms[i];
+        V3 p, n; bool o; float t = -1.0f;
+        if (g.type == PT_CUBE) t = boxIntersectionTest(g, shadowRay, p, n, o);
+        else if (g.type == PT_SPHERE) t = sphereIntersectionTest(g, shadowRay, p, n, o);
+        else if (g.type == PT_GLTF_MESH) { V2 uv; int m, tri; t = meshIntersect(S, g, shadowRay, p, n, o, uv, m, tri, cnt, false); }
+        visible = (t < 0.001f);
+    }
+    return visible;
+}
+
+/* ------------------------------------------------------------------------
+ * shaders
+ * ---------------------------------------------------------------------- */
+
+/* src/pathtrace.cu:2101-2327 */
+void shadeDiffuseMIS(const Oracle& S, PathSegment& path, const Isect& isect, V3 materialColor, Rng& rng, Counters& cnt)
+{
+    const MathFns& M = *S.M;
+    const int num_lights = (int)S.lights.size();
+    const Env& env = S.env;
+    V3 P = path.ray.origin + path.ray.direction * isect.t;
+    V3 normal = isect.normal;
+    const float MIN_PDF = 1e-6f, MAX_CONTRIBUTION = 20.0f;
+    V3 totalLight(0.0f);
+
+    float strategyChoice = rng.u01();
+    int strategy;
+    if (num_lights > 0 && env.enabled) {
+        if (strategyChoice < 0.33f) strategy = 0;
+        else if (strategyChoice < 0.66f) strategy = 1;
+        else strategy = 2;
+    } else if (num_lights > 0) strategy = (strategyChoice < 0.5f) ? 0 : 1;
+    else if (env.enabled) strategy = (strategyChoice < 0.5f) ? 1 : 2;
+    else strategy = 1;
+
+    if (strategy == 0 && num_lights > 0) {
+        int lightIdx = std::min((int)(rng.u01() * num_lights), num_lights - 1);
+        const Light& li = S.lights[lightIdx];
+        const Geom& lg = S.geoms[li.geomIdx];
+        const PtMaterial& lm = S.materials[lg.materialid];
+        V3 lightPoint = sampleLight(M, lg, rng);
+        V3 wi = lightPoint - P;
+        float dist = length(wi);
+        if (dist > 0.01f) {
+            wi /= dist;
+            float NdotL = dot(normal, wi);
+            if (NdotL > 0.0f) {
+                Ray sh{ P + normal * 0.001f, wi };
+                if (lightVisible(S, sh, li.geomIdx, dist, cnt)) {
+                    V3 lightNormal = normalize(lightPoint - lg.translation);
+                    float NdotL_light = fmax_(0.0f, dot(-wi, lightNormal));
+                    float pdfLight = 1.0f / (fmax_(li.area, 0.01f) * num_lights);
+                    float pdfBRDF = NdotL / PI;
+                    float pdfEnv = env.enabled ? envPdfImportance(M, wi, env) : 0.0f;
+                    float sumPdf = pdfLight + pdfBRDF + pdfEnv;
+                    float weight = pdfLight / fmax_(sumPdf, MIN_PDF);
+                    V3 Le = V3(lm.color) * lm.emittance;
+                    V3 f = materialColor / PI;
+                    float G = NdotL * NdotL_light / (dist * dist);
+                    float strategyProb = (num_lights > 0 && env.enabled) ? 0.33f : (num_lights > 0 || env.enabled) ? 0.5f : 1.0f;
+                    totalLight += weight * Le * f * G * (float)num_lights / (strategyProb * fmax_(pdfLight, MIN_PDF));
+                }
+            }
+        }
+    } else if (strategy == 2 && env.enabled) {
+        V3 envDir; float envPdf;
+        V3 envColor = sampleEnvImportance(M, env, rng, envDir, envPdf);
+        float NdotL = dot(normal, envDir);
+        if (NdotL > 0.0f) {
+            Ray sh{ P + normal * 0.001f, envDir };
+            if (envVisible(S, sh, cnt)) {
+                float pdfBRDF = NdotL / PI;
+                float sumPdf = envPdf + pdfBRDF;
+                float weight = envPdf / fmax_(sumPdf, MIN_PDF);
+                V3 f = materialColor / PI;
+                float strategyProb = (num_lights > 0 && env.enabled) ? 0.33f : 0.5f;
+                totalLight += weight * envColor * f * NdotL / (strategyProb * fmax_(envPdf, MIN_PDF));
+            }
+        }
+    }
+
+    V3 brdfDir = hemisphereCosine(M, normal, rng);
+    totalLight = vclamp(totalLight, V3(0.0f), V3(MAX_CONTRIBUTION));      /* glm::clamp, :2319 */
+    path.color *= materialColor + totalLight;
+    path.ray.origin = P + normal * 0.001f;
+    path.ray.direction = brdfDir;
+}
+
+/* src/pathtrace.cu:2329-2348 */
+void shadeSpecular(PathSegment& path, const Isect& isect, V3 materialColor)
+{
+    V3 normal = isect.normal;
+    V3 incident = path.ray.direction;
+    V3 reflected = normalize(incident - 2.0f * dot(incident, normal) * normal);
+    path.color *= materialColor;
+    V3 P = path.ray.origin + path.ray.direction * isect.t;
+    path.ray.origin = P + isect.normal * 0.001f;
+    path.ray.direction = reflected;
+}
+
+/* src/pathtrace.cu:2350-2415 */
+void shadeRefractive(const MathFns& M, PathSegment& path, const Isect& isect, V3 materialColor, float ior, Rng& rng)
+{
+    V3 normal = isect.normal;
+    V3 incident = normalize(path.ray.direction);
+    float cosTheta = dot(incident, normal);
+    bool entering = cosTheta < 0.0f;
+    float etaI, etaT;
+    if (entering) { etaI = 1.0f; etaT = ior; cosTheta = -cosTheta; }
+    else { etaI = ior; etaT = 1.0f; normal = -normal; }
+    float eta = etaI / etaT;
+    float sin2ThetaT = eta * eta * (1.0f - cosTheta * cosTheta);
+    V3 newDir;
+    if (sin2ThetaT > 1.0f) {
+        newDir = normalize(incident - 2.0f * dot(incident, normal) * normal);
+    } else {
+        float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+        float c = entering ? cosTheta : cosThetaT;
+        float r0 = (1.0f - eta) / (1.0f + eta);
+        r0 = r0 * r0;
+        float fresnel = r0 + (1.0f - r0) * M.pow5(1.0f - c);
+        if (rng.u01() < fresnel) newDir = reflect(incident, normal);
+        else newDir = normalize(eta * incident + (eta * cosTheta - cosThetaT) * normal);
+    }
+    path.color *= materialColor;
+    V3 P = path.ray.origin + path.ray.direction * isect.t;
+    path.ray.origin = P + newDir * 0.001f;
+    path.ray.direction = newDir;
+}
+
+/* GGX helpers: src/pathtrace.cu:1278-1337 */
+inline float GGX_D(V3 n, V3 h, float roughness)
+{
+    float alpha = roughness * roughness;
+    float alpha2 = alpha * alpha;
+    float NdotH = fmax_(0.0f, dot(n, h));
+    float NdotH2 = NdotH * NdotH;
+    float denom = NdotH2 * (alpha2 - 1.0f) + 1.0f;
+    denom = PI * denom * denom;
+    return alpha2 / fmax_(0.0001f, denom);
+}
+inline float GGX_G1(V3 n, V3 v, float roughness)
+{
+    float alpha = roughness * roughness;
+    float k = alpha / 2.0f;
+    float NdotV = fmax_(0.0f, dot(n, v));
+    float denom = NdotV * (1.0f - k) + k;
+    return NdotV / fmax_(0.0001f, denom);
+}
+inline float GGX_G(V3 n, V3 v, V3 l, float roughness) { return GGX_G1(n, v, roughness) * GGX_G1(n, l, roughness); }
+inline V3 fresnelSchlick(const MathFns& M, float cosTheta, V3 F0) { return F0 + (V3(1.0f) - F0) * M.pow5(1.0f - cosTheta); }
+V3 sampleGGX(const MathFns& M, V3 normal, float roughness, Rng& rng)
+{
+    float u = rng.u01();
+    float v = rng.u01();
+    float alpha = roughness * roughness;
+    float phi = 2.0f * PI * u;
+    float cosTheta = sqrtf((1.0f - v) / (1.0f + (alpha * alpha - 1.0f) * v));
+    float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    V3 ht(sinTheta * M.cos(phi), sinTheta * M.sin(phi), cosTheta);
+    V3 up = fabsf(normal.z) < 0.999f ? V3(0.0f, 0.0f, 1.0f) : V3(1.0f, 0.0f, 0.0f);
+    V3 tx = normalize(cross(up, normal));
+    V3 ty = cross(normal, tx);
+    return tx * ht.x + ty * ht.y + normal * ht.z;
+}
+
+/* dipole profile: src/pathtrace.cu:1518-1543 */
+V3 evaluateDipoleProfile(const MathFns& M, float r, V3 sigma_a, V3 sigma_s_prime)
+{
+    V3 sigma_t_prime = sigma_a + sigma_s_prime;
+    V3 s3 = 3.0f * sigma_a * sigma_t_prime;
+    V3 sigma_tr(sqrtf(s3.x), sqrtf(s3.y), sqrtf(s3.z));
+    V3 z_r = V3(1.0f) / sigma_t_prime;
+    V3 z_v = z_r * (1.0f + 4.0f / 3.0f * V3(1.44f));
+    V3 a = z_r * z_r + r * r;
+    V3 b = z_v * z_v + r * r;
+    V3 d_r(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z));
+    V3 d_v(sqrtf(b.x), sqrtf(b.y), sqrtf(b.z));
+    V3 C_phi = V3(0.25f) / PI;
+    V3 er = -sigma_tr * d_r, ev = -sigma_tr * d_v;
+    V3 expr(M.exp(er.x), M.exp(er.y), M.exp(er.z));
+    V3 expv(M.exp(ev.x), M.exp(ev.y), M.exp(ev.z));
+    V3 result = C_phi * (z_r * (sigma_tr + V3(1.0f) / d_r) * expr / (d_r * d_r) +
+                         z_v * (sigma_tr + V3(1.0f) / d_v) * expv / (d_v * d_v));
+    return vclamp(result, V3(0.0f), V3(1.0f));
+}
+/* src/pathtrace.cu:1546-1565 */
+void computeSSCoefficients(const PtMaterial& m, V3& sigma_a, V3& sigma_s_prime)
+{
+    V3 A(m.subsurfaceColor);
+    V3 safeRadius = vmax(V3(m.subsurfaceRadiusRGB) * m.subsurfaceScale, V3(0.001f));
+    sigma_s_prime = V3(1.0f) / safeRadius;
+    sigma_a = sigma_s_prime * (V3(1.0f) - A) * 0.01f;
+    sigma_a = vclamp(sigma_a, V3(0.001f), V3(10.0f));
+    sigma_s_prime = vclamp(sigma_s_prime, V3(0.1f), V3(100.0f));
+}
+/* src/pathtrace.cu:1568-1609 */
+V3 sampleSSExitPoint(const MathFns& M, V3 entry, V3 normal, const PtMaterial& m, Rng& rng)
+{
+    float avgRadius = (m.subsurfaceRadiusRGB[0] + m.subsurfaceRadiusRGB[1] + m.subsurfaceRadiusRGB[2]) / 3.0f;
+    avgRadius *= m.subsurfaceScale;
+    avgRadius = gclamp(avgRadius, 0.001f, 1.0f);
+    float u = rng.u01();
+    float distance = -M.log(1.0f - u * 0.9f) * avgRadius;
+    distance = gclamp(distance, 0.001f, avgRadius * 3.0f);
+    float theta = 2.0f * PI * rng.u01();
+    float phi = M.acos(1.0f - rng.u01());
+    V3 localDir(M.sin(phi) * M.cos(theta), M.sin(phi) * M.sin(theta), M.cos(phi));
+    V3 tangent = (fabsf(normal.x) > fabsf(normal.y)) ? normalize(V3(-normal.z, 0, normal.x)) : normalize(V3(0, -normal.z, normal.y));
+    V3 bitangent = cross(normal, tangent);
+    V3 worldDir = tangent * localDir.x + bitangent * localDir.y - normal * localDir.z;
+    return entry + normalize(worldDir) * distance;
+}
+/* src/pathtrace.cu:1612-1702 */
+bool sampleSubsurfacePath(const MathFns& M, PathSegment& path, V3 P, V3 normal, const PtMaterial& m, V3 materialColor, Rng& rng)
+{
+    if (m.subsurfaceEnabled == 0 || m.metallic > 0.5f) return false;
+    float sssProb = 0.3f * (1.0f - m.metallic);
+    sssProb = gclamp(sssProb, 0.1f, 0.3f);
+    if (rng.u01() > sssProb) return false;
+
+    V3 exitPoint = sampleSSExitPoint(M, P, normal, m, rng);
+    float distance = length(exitPoint - P);
+    V3 sigma_a, sigma_s_prime;
+    computeSSCoefficients(m, sigma_a, sigma_s_prime);
+    V3 bssrdf = evaluateDipoleProfile(M, distance, sigma_a, sigma_s_prime);
+    V3 e = -sigma_a * distance;
+    V3 transmittance(M.exp(e.x), M.exp(e.y), M.exp(e.z));
+    transmittance = vclamp(transmittance, V3(0.0f), V3(1.0f));
+    V3 throughput = bssrdf * transmittance * V3(m.subsurfaceColor);
+    throughput = throughput * mix(V3(1.0f), materialColor, 0.5f);
+    throughput *= (1.0f / sssProb);
+    float maxComponent = fmax_(fmax_(throughput.x, throughput.y), throughput.z);
+    if (maxComponent > 2.0f) throughput *= 2.0f / maxComponent;
+    path.color *= throughput;
+
+    V3 exitNormal = normal;
+    float r1 = rng.u01();
+    float r2 = rng.u01();
+    float sinTheta = sqrtf(r1);
+    float cosTheta = sqrtf(1.0f - r1);
+    float phi = 2.0f * PI * r2;
+    V3 localDir(sinTheta * M.cos(phi), sinTheta * M.sin(phi), cosTheta);
+    V3 tangent = (fabsf(exitNormal.x) > fabsf(exitNormal.y)) ? normalize(V3(-exitNormal.z, 0, exitNormal.x))
+                                                              : normalize(V3(0, -exitNormal.z, exitNormal.y));
+    V3 bitangent = cross(exitNormal, tangent);
+    V3 worldDir = tangent * localDir.x + bitangent * localDir.y + exitNormal * localDir.z;
+    path.ray.origin = exitPoint + exitNormal * 0.001f;
+    path.ray.direction = normalize(worldDir);
+    path.remainingBounces--;
+    return true;
+}
+
+/* Cook-Torrance + Lambert for one light direction: src/pathtrace.cu:1898-1918, :1996-2016 */
+inline V3 pbrBrdf(const MathFns& M, V3 normal, V3 wo, V3 wi, float NdotL, float roughness, float metallic, V3 albedo, V3 F0,
+                  float& D, float& NdotH, float& VdotH)
+{
+    V3 h = normalize(wi + wo);
+    float NdotV = fmax_(0.0f, dot(normal, wo));
+    NdotH = fmax_(0.0f, dot(normal, h));
+    VdotH = fmax_(0.0f, dot(wo, h));
+    D = GGX_D(normal, h, roughness);
+    float G = GGX_G(normal, wo, wi, roughness);
+    V3 F = fresnelSchlick(M, VdotH, F0);
+    V3 numerator = D * G * F;
+    float denominator = 4.0f * NdotV * NdotL;
+    V3 specular = numerator / fmax_(0.001f, denominator);
+    V3 kS = F;
+    V3 kD = V3(1.0f) - kS;
+    kD *= 1.0f - metallic;
+    V3 diffuse = kD * albedo / PI;
+    return diffuse + specular;
+}
+
+/* src/pathtrace.cu:1708-2099 */
+void shadePBR(const Oracle& S, PathSegment& path, const Isect& isect, const PtMaterial& material, V3 texturedColor,
+              float textureAlpha, Rng& rng, Counters& cnt)
+{
+    const MathFns& M = *S.M;
+    int num_lights = (int)S.lights.size();
+    const Env& env = S.env;
+    bool envMapValid = env.enabled && env.hasData() && env.width > 0 && env.height > 0;
+
+    V3 P = path.ray.origin + path.ray.direction * isect.t;
+    V3 normal = isect.normal;
+
+    if (material.subsurfaceEnabled > 0 && material.metallic < 0.5f) {
+        if (sampleSubsurfacePath(M, path, P, normal, material, texturedColor, rng)) return;
+    }
+
+    V3 wo = -path.ray.direction;
+    V3 albedo = texturedColor;
+    float roughness = gclamp(material.roughness, 0.02f, 1.0f);
+    float metallic = material.metallic;
+
+    float combinedTransparency = material.transparency;
+    if (textureAlpha < 1.0f) {
+        float textureTransparency = 1.0f - textureAlpha;
+        combinedTransparency = 1.0f - ((1.0f - combinedTransparency) * (1.0f - textureTransparency));
+    }
+
+    if (combinedTransparency > 0.0f && rng.u01() < combinedTransparency) {
+        float ior = material.indexOfRefraction > 0 ? material.indexOfRefraction : 1.5f;
+        bool entering = dot(normal, wo) > 0;
+        V3 n = entering ? normal : -normal;
+        float eta = entering ? (1.0f / ior) : ior;
+        float cosTheta = dot(n, wo);
+        float k = 1.0f - eta * eta * (1.0f - cosTheta * cosTheta);
+        V3 newDir;
+        if (k < 0.0f || roughness > 0.8f) {
+            newDir = path.ray.direction;
+            path.ray.origin = P - n * 0.001f;
+        } else {
+            newDir = normalize(eta * (-wo) + (eta * cosTheta - sqrtf(k)) * n);
+            path.ray.origin = P - n * 0.001f;
+        }
+        if (roughness > 0.1f && roughness < 0.8f) {
+            /* constructor arguments drawn left to right (x, y, z), as nvcc and clang evaluate them */
+            float sx = rng.u01() - 0.5f;
+            float sy = rng.u01() - 0.5f;
+            float sz = rng.u01() - 0.5f;
+            V3 scatter = V3(sx, sy, sz) * roughness * 0.2f;
+            newDir = normalize(newDir + scatter);
+        }
+        path.ray.direction = newDir;
+        path.color *= mix(V3(1.0f), albedo, 1.0f - combinedTransparency);
+        return;
+    }
+
+    V3 F0 = V3(0.04f);
+    F0 = mix(F0, albedo, metallic);
+    const float MIN_PDF = 1e-6f, MAX_CONTRIBUTION = 10.0f;
+    V3 directLight(0.0f);
+
+    float strategyChoice = rng.u01();
+    int strategy = 1;
+    if (num_lights > 0 && envMapValid) {
+        if (strategyChoice < 0.33f) strategy = 0;
+        else if (strategyChoice < 0.66f) strategy = 1;
+        else strategy = 2;
+    } else if (num_lights > 0 && !envMapValid) strategy = (strategyChoice < 0.5f) ? 0 : 1;
+    else if (num_lights == 0 && envMapValid) strategy = (strategyChoice < 0.5f) ? 1 : 2;
+    else strategy = 1;
+
+    if (strategy == 0 && num_lights > 0) {
+        int lightIdx = std::min((int)(rng.u01() * num_lights), num_lights - 1);
+        const Light& li = S.lights[lightIdx];
+        const Geom& lg = S.geoms[li.geomIdx];
+        const PtMaterial& lm = S.materials[lg.materialid];
+        V3 lightPoint = sampleLight(M, lg, rng);
+        V3 wi = lightPoint - P;
+        float dist = length(wi);
+        if (dist > 0.01f) {
+            wi /= dist;
+            float NdotL = dot(normal, wi);
+            if (NdotL > 0.0f) {
+                Ray sh{ P + normal * 0.001f, wi };
+                if (lightVisible(S, sh, li.geomIdx, dist, cnt)) {
+                    float D, NdotH, VdotH;
+                    V3 brdf = pbrBrdf(M, normal, wo, wi, NdotL, roughness, metallic, albedo, F0, D, NdotH, VdotH);
+                    V3 lightNormal = normalize(lightPoint - lg.translation);
+                    float NdotL_light = fmax_(0.0f, dot(-wi, lightNormal));
+                    float pdfLight = 1.0f / (fmax_(li.area, 0.01f) * num_lights);
+                    float pdfBRDF = (NdotL / PI) * (1.0f - metallic) + (D * NdotH / (4.0f * VdotH)) * metallic;
+                    float pdfEnv = envMapValid ? envPdfImportance(M, wi, env) : 0.0f;
+                    float sumPdf = pdfLight + pdfBRDF + pdfEnv;
+                    float weight = pdfLight / fmax_(sumPdf, MIN_PDF);
+                    V3 Le = V3(lm.color) * lm.emittance;
+                    float geometryTerm = NdotL * NdotL_light / (dist * dist);
+                    float strategyProb;
+                    if (num_lights > 0 && envMapValid) strategyProb = 0.33f;
+                    else if (num_lights > 0 || envMapValid) strategyProb = 0.5f;
+                    else strategyProb = 1.0f;
+                    directLight += weight * brdf * Le * geometryTerm * (float)num_lights / (strategyProb * fmax_(pdfLight, MIN_PDF));
+                }
+            }
+        }
+    } else if (strategy == 2 && envMapValid) {
+        V3 envDir; float envPdf;
+        V3 envColor = sampleEnvImportance(M, env, rng, envDir, envPdf);
+        float NdotL = dot(normal, envDir);
+        if (NdotL > 0.0f) {
+            Ray sh{ P + normal * 0.001f, envDir };
+            if (envVisible(S, sh, cnt)) {
+                float D, NdotH, VdotH;
+                V3 brdf = pbrBrdf(M, normal, wo, envDir, NdotL, roughness, metallic, albedo, F0, D, NdotH, VdotH);
+                float pdfBRDF = (NdotL / PI) * (1.0f - metallic) + (D * NdotH / (4.0f * VdotH)) * metallic;
+                float sumPdf = envPdf + pdfBRDF;
+                float weight = envPdf / fmax_(sumPdf, MIN_PDF);
+                float strategyProb;
+                if (num_lights > 0 && envMapValid) strategyProb = 0.33f;
+                else if (envMapValid) strategyProb = 0.5f;
+                else strategyProb = 1.0f;
+                directLight += weight * brdf * envColor * NdotL / (strategyProb * fmax_(envPdf, MIN_PDF));
+            }
+        }
+    }
+
+    directLight = vclamp(directLight, V3(0.0f), V3(MAX_CONTRIBUTION));
+
+    float specularProbability = 0.5f + 0.5f * metallic;
+    if (rng.u01() < specularProbability) {
+        V3 h = sampleGGX(M, normal, roughness, rng);
+        V3 wi = reflect(-wo, h);
+        if (dot(wi, normal) > 0.0f) {
+            float VdotH = fmax_(0.0f, dot(wo, h));
+            V3 F = fresnelSchlick(M, VdotH, F0);
+            V3 specColor = mix(V3(1.0f), albedo, metallic);
+            path.color *= (specColor * F / specularProbability) + directLight;
+            path.ray.origin = P + normal * 0.001f;
+            path.ray.direction = wi;
+            path.prevIsSpecular = true;
+        } else {
+            path.remainingBounces = 0;
+            path.color = V3(0.0f);
+        }
+    } else {
+        if (metallic < 1.0f) {
+            V3 wi = hemisphereCosine(M, normal, rng);
+            V3 diffuseColor = albedo * (1.0f - metallic);
+            path.color *= (diffuseColor / (1.0f - specularProbability)) + directLight;
+            path.ray.origin = P + normal * 0.001f;
+            path.ray.direction = wi;
+            path.prevIsSpecular = false;
+        } else {
+            path.remainingBounces = 0;
+            path.color = V3(0.0f);
+        }
+    }
+    path.remainingBounces--;
+}
+
+/* shadeMaterialMIS for one slot: src/pathtrace.cu:2455-2626 */
+void shadeSlot(const Oracle& S, int iter, int currentBounce, int idx, PathSegment& path, const Isect& isect,
+               bool firstBounce, Counters& cnt)
+{
+    const MathFns& M = *S.M;
+    if (path.remainingBounces <= 0) return;
+    Rng rng(iter, idx, path.remainingBounces);
+
+    if (currentBounce >= 3 /* RR_START_BOUNCE, src/sceneStructs.h:12 */) {
+        float throughput = 0.2126f * path.color.x + 0.7152f * path.color.y + 0.0722f * path.color.z;
+        float survivalProb = gclamp(throughput, 0.05f, 0.95f);
+        if (rng.u01() >= survivalProb) {
+            path.remainingBounces = 0;
+            path.color = V3(0.0f);
+            return;
+        }
+        path.color /= survivalProb;
+    }
+
+    if (isect.t > 0.0f) {
+        PtMaterial material = S.materials[isect.materialId];
+        V3 materialColor(material.color);
+        float textureAlpha = 1.0f;
+        const int num_textures = (int)S.textures.size();
+
+        if (material.baseColorTextureIdx >= 0 && material.baseColorTextureIdx < num_textures) {
+            V4 c = sampleTexture(S.textures[material.baseColorTextureIdx], isect.uv);
+            materialColor = V3(c.x, c.y, c.z);
+            textureAlpha = c.w;
+            materialColor *= V3(material.color);
+        }
+        if (material.metallicRoughnessTextureIdx >= 0 && material.metallicRoughnessTextureIdx < num_textures) {
+            V4 mr = sampleTexture(S.textures[material.metallicRoughnessTextureIdx], isect.uv);
+            material.metallic *= mr.z;
+            material.roughness *= mr.y;
+        }
+        if (material.emissiveTextureIdx >= 0 && material.emissiveTextureIdx < num_textures) {
+            V4 e4 = sampleTexture(S.textures[material.emissiveTextureIdx], isect.uv);
+            V3 emissive(e4.x, e4.y, e4.z);
+            if (length(emissive) > 0.0f) {
+                path.color *= emissive * V3(material.emissiveFactor);
+                path.remainingBounces = 0;
+                return;
+            }
+        }
+        if (material.emittance > 0.0f) {
+            path.color *= (materialColor * material.emittance);
+            path.remainingBounces = 0;
+            return;
+        }
+        path.remainingBounces--;
+        if (path.remainingBounces <= 0) {
+            path.color = V3(0.0f);
+            return;
+        }
+        switch (material.type) {
+        case PT_DIFFUSE:
+            path.prevIsSpecular = false;
+            shadeDiffuseMIS(S, path, isect, materialColor, rng, cnt);
+            break;
+        case PT_SPECULAR:
+            path.prevIsSpecular = true;
+            shadeSpecular(path, isect, materialColor);
+            break;
+        case PT_REFRACTIVE:
+            path.prevIsSpecular = true;
+            shadeRefractive(M, path, isect, materialColor, material.indexOfRefraction, rng);
+            break;
+        case PT_PBR:
+            path.prevIsSpecular = (material.roughness < 0.1f && material.metallic > 0.5f);
+            shadePBR(S, path, isect, material, materialColor, textureAlpha, rng, cnt);
+            break;
+        default:
+            path.prevIsSpecular = false;
+            break;
+        }
+    } else {
+        if (S.env.enabled) {
+            V3 envColor = sampleEnvironmentMap(M, path.ray.direction, S.env);
+            if (firstBounce) path.color *= envColor;
+            else if (path.prevIsSpecular) path.color *= envColor;
+            else path.color *= envColor * 0.5f;
+        } else {
+            path.color *= V3(0.0f);
+        }
+        path.remainingBounces = 0;
+    }
+}
+
+/* generateRayFromCamera for one pixel: src/pathtrace.cu:694-745 */
+void cameraRay(const PtCamera& cam, int iter, int traceDepth, int x, int y, PathSegment& seg)
+{
+    int index = x + (y * cam.resolution[0]);
+    seg.ray.origin = V3(cam.position);
+    seg.color = V3(1.0f, 1.0f, 1.0f);
+    const int GRID = 2, CELLS = GRID * GRID;
+    Rng rng(iter, index, 0);
+    int cellIndex = iter % CELLS;
+    int cellX = cellIndex % GRID;
+    int cellY = cellIndex / GRID;
+    float cellSize = 1.0f / (float)GRID;
+    float jitterX = (cellX + rng.u01()) * cellSize;
+    float jitterY = (cellY + rng.u01()) * cellSize;
+    float pixelX = (float)x + jitterX - 0.5f;
+    float pixelY = (float)y + jitterY - 0.5f;
+    seg.ray.direction = normalize(V3(cam.view)
+        - V3(cam.right) * cam.pixelLength[0] * (pixelX - (float)cam.resolution[0] * 0.5f)
+        - V3(cam.up) * cam.pixelLength[1] * (pixelY - (float)cam.resolution[1] * 0.5f));
+    seg.pixelIndex = index;
+    seg.remainingBounces = traceDepth;
+    /* prevIsSpecular is left as it was (the kernel never writes it); it is always
+       rewritten by the first shade before any read, so the value is irrelevant */
+}
+
+/* ------------------------------------------------------------------------
+ * BVH build — src/bvh.cpp:30-238 restated
+ * ---------------------------------------------------------------------- */
+struct Box {
+    V3 mn = V3(FLT_MAX), mx = V3(-FLT_MAX);
+    void grow(V3 p) { mn = vmin(mn, p); mx = vmax(mx, p); }
+    void grow(const Box& b) { mn = vmin(mn, b.mn); mx = vmax(mx, b.mx); }
+    V3 centroid() const { return (mn + mx) * 0.5f; }
+    float area() const { V3 d = mx - mn; return 2.0f * (d.x * d.y + d.y * d.z + d.z * d.x); }
+    int longestAxis() const { V3 d = mx - mn; if (d.x > d.y && d.x > d.z) return 0; if (d.y > d.z) return 1; return 2; }
+};
+struct TriRef { int index; Box bounds; V3 centroid; };
+
+struct BvhBuilder {
+    std::vector<PtBvhNode> nodes;
+    std::vector<int32_t> indices;
+    std::vector<TriRef> refs;
+    int maxDepth = 24, statDepth = 0;
+
+    void build(const PtTriangle* tris, int n, int maxDepthParam)
+    {
+        maxDepth = maxDepthParam;
+        refs.reserve(n);
+        for (int i = 0; i < n; i++) {
+            TriRef r; r.index = i;
+            r.bounds.grow(V3(tris[i].v0)); r.bounds.grow(V3(tris[i].v1)); r.bounds.grow(V3(tris[i].v2));
+            r.centroid = r.bounds.centroid();
+            refs.push_back(r);
+        }
+        nodes.reserve(2 * (size_t)n + 1);
+        indices.reserve(n);
+        recurse(0, n, 0);
+    }
+    int makeLeaf(int nodeIdx, int start, int end)
+    {
+        PtBvhNode& node = nodes[nodeIdx];
+        node.leftChild = -1; node.rightChild = -1;
+        node.triangleStart = (int)indices.size();
+        node.triangleCount = end - start;
+        for (int i = start; i < end; i++) indices.push_back(refs[i].index);
+        return nodeIdx;
+    }
+    int recurse(int start, int end, int depth)
+    {
+        int nodeIdx = (int)nodes.size();
+        nodes.push_back(PtBvhNode{ { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX }, 0, 0, 0, 0 });
+        statDepth = std::max(statDepth, depth);
+        Box b;
+        for (int i = start; i < end; i++) b.grow(refs[i].bounds);
+        nodes[nodeIdx].bmin[0] = b.mn.x; nodes[nodeIdx].bmin[1] = b.mn.y; nodes[nodeIdx].bmin[2] = b.mn.z;
+        nodes[nodeIdx].bmax[0] = b.mx.x; nodes[nodeIdx].bmax[1] = b.mx.y; nodes[nodeIdx].bmax[2] = b.mx.z;
+        int count = end - start;
+        if (depth >= maxDepth || count <= 4 /* BVH_MAX_LEAF_TRIANGLES */) return makeLeaf(nodeIdx, start, end);
+        int mid;
+        if (count > 32) mid = splitSAH(start, end);
+        else mid = splitMiddle(start, end, b.longestAxis());
+        if (mid == start || mid == end) return makeLeaf(nodeIdx, start, end);
+        int l = recurse(start, mid, depth + 1);
+        nodes[nodeIdx].leftChild = l;
+        int r = recurse(mid, end, depth + 1);
+        nodes[nodeIdx].rightChild = r;
+        nodes[nodeIdx].triangleStart = -1;
+        nodes[nodeIdx].triangleCount = 0;
+        return nodeIdx;
+    }
+    int splitMiddle(int start, int end, int axis)
+    {
+        int mid = (start + end) / 2;
+        std::nth_element(refs.begin() + start, refs.begin() + mid, refs.begin() + end,
+                         [axis](const TriRef& a, const TriRef& b) { return a.centroid[axis] < b.centroid[axis]; });
+        return mid;
+    }
+    float evalSAH(int start, int end, int axis, float splitPos, int& outSplit)
+    {
+        Box lb, rb; int lc = 0, rc = 0;
+        for (int i = start; i < end; i++) {
+            if (refs[i].centroid[axis] < splitPos) { lb.grow(refs[i].bounds); lc++; }
+            else { rb.grow(refs[i].bounds); rc++; }
+        }
+        outSplit = start + lc;
+        if (lc == 0 || rc == 0) return FLT_MAX;
+        float la = lb.area(), ra = rb.area(), total = la + ra;
+        return 1.0f + 1.0f * (la / total * lc + ra / total * rc);
+    }
+    int splitSAH(int start, int end)
+    {
+        if (end - start <= 2) return (start + end) / 2;
+        Box cb;
+        for (int i = start; i < end; i++) cb.grow(refs[i].centroid);
+        int bestAxis = -1; float bestPos = 0, bestCost = FLT_MAX; int bestSplit = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float lo = cb.mn[axis], hi = cb.mx[axis];
+            if (lo == hi) continue;
+            for (int i = 1; i < 12 /* BVH_SAH_SAMPLES */; i++) {
+                float t = i / (float)12;
+                float pos = lo + t * (hi - lo);
+                int split;
+                float cost = evalSAH(start, end, axis, pos, split);
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestPos = pos; bestSplit = split; }
+            }
+        }
+        if (bestAxis == -1 || bestSplit <= start || bestSplit >= end) return splitMiddle(start, end, cb.longestAxis());
+        auto pivot = std::partition(refs.begin() + start, refs.begin() + end,
+                                    [bestAxis, bestPos](const TriRef& r) { return r.centroid[bestAxis] < bestPos; });
+        return (int)(pivot - refs.begin());
+    }
+};
+
+/* env-map CDFs: src/pathtrace.cu:336-425 */
+void buildEnvDistribution(Env& env)
+{
+    if (!env.enabled || env.data.empty()) { env.totalPower = 0.0f; return; }
+    const int W = env.width, H = env.height;
+    std::vector<float> lum((size_t)W * H), rowPowers(H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            size_t idx = (size_t)y * W + x;
+            V3 c = env.data[idx];
+            lum[idx] = 0.299f * c.x + 0.587f * c.y + 0.114f * c.z;
+            float theta = (y + 0.5f) * PI / H;
+            lum[idx] *= sinf(theta);          /* host code in the reference: always libm */
+        }
+    env.conditionalCDFs.resize((size_t)W * H);
+    for (int y = 0; y < H; y++) {
+        float rowSum = 0.0f;
+        for (int x = 0; x < W; x++) { size_t idx = (size_t)y * W + x; rowSum += lum[idx]; env.conditionalCDFs[idx] = rowSum; }
+        rowPowers[y] = rowSum;
+        if (rowSum > 0) { float inv = 1.0f / rowSum; for (int x = 0; x < W; x++) env.conditionalCDFs[(size_t)y * W + x] *= inv; }
+    }
+    env.marginalCDF.resize(H);
+    float total = 0.0f;
+    for (int y = 0; y < H; y++) { total += rowPowers[y]; env.marginalCDF[y] = total; }
+    env.totalPower = total;
+    if (total > 0) { float inv = 1.0f / total; for (int y = 0; y < H; y++) env.marginalCDF[y] *= inv; }
+}
+
+/* src/pathtrace.cu:217-230 */
+float geomArea(const Geom& g)
+{
+    if (g.type == PT_SPHERE) { float radius = g.scale.x * 0.5f; return 4.0f * PI * radius * radius; }
+    if (g.type == PT_CUBE) { float sx = g.scale.x, sy = g.scale.y, sz = g.scale.z; return 2.0f * (sx * sy + sy * sz + sz * sx); }
+    return 1.0f;
+}
+
+} // namespace
+
+/* ==========================================================================
+ * C interface
+ * ======================================================================== */
+extern "C" {
+
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+int oracle_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* pathtraceInit: src/pathtrace.cu:428-576 */
+Oracle* oracle_create(const PtSceneDesc* d)
+{
+    Oracle* o = new Oracle();
+    o->cam = d->camera;
+    o->traceDepth = d->traceDepth;
+    o->materials.assign(d->materials, d->materials + d->materialCount);
+    for (int i = 0; i < d->geomCount; i++) {
+        const PtGeom& g = d->geoms[i];
+        Geom G;
+        G.type = g.type; G.materialid = g.materialid;
+        G.translation = V3(g.translation); G.rotation = V3(g.rotation); G.scale = V3(g.scale);
+        G.transform = loadM4(g.transform); G.inverseTransform = loadM4(g.inverseTransform); G.invTranspose = loadM4(g.invTranspose);
+        G.meshIndex = g.meshIndex; G.triangleStart = -1; G.triangleCount = 0; G.bvhIndex = -1;
+        o->geoms.push_back(G);
+    }
+    /* meshes: concatenate triangles in geom order (src/pathtrace.cu:483-505), one BVH per mesh (:269-334) */
+    o->meshes.resize(d->meshCount);
+    for (int m = 0; m < d->meshCount; m++) {
+        const PtMesh& pm = d->meshes[m];
+        Mesh& M = o->meshes[m];
+        M.tris.assign(pm.triangles, pm.triangles + pm.triangleCount);
+        if (pm.nodes && pm.triangleIndices) {
+            M.nodes.assign(pm.nodes, pm.nodes + pm.nodeCount);
+            M.indices.assign(pm.triangleIndices, pm.triangleIndices + pm.triangleIndexCount);
+        } else if (pm.triangleCount > 0) {
+            BvhBuilder b; b.build(pm.triangles, pm.triangleCount, 24 /* BVH_MAX_TREE_DEPTH, src/pathtrace.cu:194 */);
+            M.nodes.swap(b.nodes); M.indices.swap(b.indices);
+        }
+    }
+    int offset = 0, bvhIdx = 0;
+    for (auto& G : o->geoms) {
+        if (G.type == PT_GLTF_MESH && G.meshIndex >= 0 && G.meshIndex < (int)o->meshes.size()) {
+            Mesh& M = o->meshes[G.meshIndex];
+            G.triangleStart = offset;
+            G.triangleCount = (int)M.tris.size();
+            o->triangles.insert(o->triangles.end(), M.tris.begin(), M.tris.end());
+            offset += G.triangleCount;
+            G.bvhIndex = bvhIdx++;
+            o->anyBvh = true;
+        }
+    }
+    for (int t = 0; t < d->textureCount; t++) {
+        Tex T; T.width = d->textures[t].width; T.height = d->textures[t].height; T.components = d->textures[t].components;
+        T.data.assign(d->textures[t].data, d->textures[t].data + (size_t)T.width * T.height * T.components);
+        o->textures.push_back(std::move(T));
+    }
+    /* lights: src/pathtrace.cu:232-267 */
+    float totalArea = 0.0f;
+    for (int i = 0; i < (int)o->geoms.size(); i++) {
+        int matId = o->geoms[i].materialid;
+        if (matId >= 0 && matId < (int)o->materials.size() && o->materials[matId].emittance > 0.0f) {
+            Light L; L.geomIdx = i; L.area = geomArea(o->geoms[i]); L.pdf = 0;
+            totalArea += L.area;
+            o->lights.push_back(L);
+        }
+    }
+    for (auto& L : o->lights) L.pdf = L.area / totalArea;
+    /* env map: src/pathtrace.cu:453-476 */
+    o->env.enabled = d->env.enabled && d->env.data && d->env.width > 0 && d->env.height > 0;
+    if (o->env.enabled) {
+        o->env.width = d->env.width; o->env.height = d->env.height; o->env.intensity = d->env.intensity;
+        size_t n = (size_t)d->env.width * d->env.height;
+        o->env.data.resize(n);
+        for (size_t i = 0; i < n; i++) o->env.data[i] = V3(d->env.data + 3 * i);
+        buildEnvDistribution(o->env);
+    }
+    size_t N = (size_t)o->cam.resolution[0] * o->cam.resolution[1];
+    o->image.assign(N, V3(0.0f));
+    o->paths.resize(N); o->pathsSorted.resize(N);
+    o->isects.resize(N); o->isectsSorted.resize(N);
+    o->keys.resize(N); o->order.resize(N);
+    for (auto& p : o->paths) p.prevIsSpecular = false;
+    for (auto& p : o->pathsSorted) p.prevIsSpecular = false;
+    memset(&o->stats, 0, sizeof(o->stats));
+    return o;
+}
+
+void oracle_destroy(Oracle* o) { delete o; }
+void oracle_set_math(Oracle* o, int mode) { o->M = (mode == ORACLE_MATH_DET) ? &kDet : &kLibm; }
+void oracle_set_option(Oracle* o, int option, int value)
+{
+    if (option == PT_OPT_MATERIAL_SORT) o->sortByMaterial = value != 0;
+    else if (option == PT_OPT_USE_BVH) o->useBvh = value != 0;
+    else if (option == PT_OPT_COUNTERS) o->counters = value != 0;
+}
+void oracle_clear(Oracle* o)
+{
+    std::fill(o->image.begin(), o->image.end(), V3(0.0f));
+    memset(&o->stats, 0, sizeof(o->stats));
+    o->cnt = Counters();
+}
+
+/* pathtrace(): src/pathtrace.cu:2659-2930 with thrust::sort_by_key == stable sort on int keys
+ * (:2779-2781) and thrust::remove_if == stable compaction (:2865-2868). */
+void oracle_trace(Oracle* o, int iter)
+{
+    const int W = o->cam.resolution[0], H = o->cam.resolution[1];
+    const int N = W * H;
+    const int traceDepth = o->traceDepth;
+
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < N; idx++) cameraRay(o->cam, iter, traceDepth, idx % W, idx / W, o->paths[idx]);
+
+    int depth = 0, n = N;
+    bool firstBounce = true;
+    memset(o->stats.lastLive, 0, sizeof(o->stats.lastLive));
+    uint64_t cn = 0, ct = 0, ch = 0;
+    while (true) {
+        if (depth < PT_MAX_DEPTH) o->stats.lastLive[depth] = (uint32_t)n;
+        o->stats.pathBounces += (uint64_t)n;
+        /* intersect (records start from the memset of :2732) */
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : cn, ct, ch)
+        for (int i = 0; i < n; i++) {
+            Counters c;
+            closestHit(*o, o->paths[i].ray, o->isects[i], c, false);
+            cn += c.nodes; ct += c.tris; ch += c.meshHits;
+        }
+        depth++;
+        /* material sort: keys :2417-2431, stable sort :2781, gather :2433-2447, swap :2793-2799 */
+        if (o->sortByMaterial && n > 0) {
+            for (int i = 0; i < n; i++) {
+                o->keys[i] = (o->isects[i].t > 0.0f) ? o->isects[i].materialId : INT_MAX;
+                o->order[i] = i;
+            }
+            std::stable_sort(o->order.begin(), o->order.begin() + n, [&](int a, int b) { return o->keys[a] < o->keys[b]; });
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < n; i++) {
+                o->pathsSorted[i] = o->paths[o->order[i]];
+                o->isectsSorted[i] = o->isects[o->order[i]];
+            }
+            o->paths.swap(o->pathsSorted);
+            o->isects.swap(o->isectsSorted);
+        }
+        /* shade :2829-2847 */
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : cn, ct, ch)
+        for (int i = 0; i < n; i++) {
+            Counters c;
+            shadeSlot(*o, iter, depth, i, o->paths[i], o->isects[i], firstBounce, c);
+            cn += c.nodes; ct += c.tris; ch += c.meshHits;
+        }
+        firstBounce = false;
+        /* gatherTerminatedPaths :2641-2653 */
+        for (int i = 0; i < n; i++)
+            if (o->paths[i].remainingBounces == 0) o->image[o->paths[i].pixelIndex] += o->paths[i].color;
+        /* compaction :2865-2871 */
+        int w = 0;
+        for (int i = 0; i < n; i++)
+            if (!(o->paths[i].remainingBounces <= 0)) { if (w != i) o->paths[w] = o->paths[i]; w++; }
+        n = w;
+        if (n == 0 || depth >= traceDepth) break;
+    }
+    /* finalGather :2630-2639 */
+    for (int i = 0; i < n; i++) o->image[o->paths[i].pixelIndex] += o->paths[i].color;
+    o->stats.lastDepth = (uint32_t)depth;
+    o->stats.iterations++;
+    o->stats.nodesVisited += cn; o->stats.trisTested += ct; o->stats.meshHits += ch;
+}
+
+void oracle_image(Oracle* o, float* rgb)
+{
+    for (size_t i = 0; i < o->image.size(); i++) { rgb[3 * i] = o->image[i].x; rgb[3 * i + 1] = o->image[i].y; rgb[3 * i + 2] = o->image[i].z; }
+}
+
+/* sendImageToPBO: src/pathtrace.cu:145-166 (the 255.0 is a double) */
+void oracle_display(Oracle* o, int iter, uint8_t* rgba)
+{
+    for (size_t i = 0; i < o->image.size(); i++) {
+        V3 pix = o->image[i];
+        int r = std::min(std::max((int)(pix.x / iter * 255.0), 0), 255);
+        int g = std::min(std::max((int)(pix.y / iter * 255.0), 0), 255);
+        int b = std::min(std::max((int)(pix.z / iter * 255.0), 0), 255);
+        rgba[4 * i] = (uint8_t)r; rgba[4 * i + 1] = (uint8_t)g; rgba[4 * i + 2] = (uint8_t)b; rgba[4 * i + 3] = 0;
+    }
+}
+
+void oracle_stats(Oracle* o, PtStats* out) { *out = o->stats; }
+
+void oracle_camera_rays(Oracle* o, int iter, float* origins, float* directions)
+{
+    const int W = o->cam.resolution[0], H = o->cam.resolution[1];
+    for (int idx = 0; idx < W * H; idx++) {
+        PathSegment s;
+        cameraRay(o->cam, iter, o->traceDepth, idx % W, idx / W, s);
+        origins[3 * idx] = s.ray.origin.x; origins[3 * idx + 1] = s.ray.origin.y; origins[3 * idx + 2] = s.ray.origin.z;
+        directions[3 * idx] = s.ray.direction.x; directions[3 * idx + 1] = s.ray.direction.y; directions[3 * idx + 2] = s.ray.direction.z;
+    }
+}
+
+static void intersectRays(Oracle* o, const float* origins, const float* directions, int n, PtHit* out, bool linear)
+{
+    uint64_t cn = 0, ct = 0, ch = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : cn, ct, ch)
+    for (int i = 0; i < n; i++) {
+        Ray r{ V3(origins + 3 * i), V3(directions + 3 * i) };
+        Isect is; Counters c;
+        closestHit(*o, r, is, c, linear);
+        cn += c.nodes; ct += c.tris; ch += c.meshHits;
+        out[i].t = is.t; out[i].geom = is.geom; out[i].triangle = is.tri;
+        out[i].materialId = is.t > 0.0f ? is.materialId : -1;
+        out[i].normal[0] = is.normal.x; out[i].normal[1] = is.normal.y; out[i].normal[2] = is.normal.z;
+        out[i].uv[0] = is.uv.x; out[i].uv[1] = is.uv.y;
+    }
+    o->stats.nodesVisited += cn; o->stats.trisTested += ct; o->stats.meshHits += ch;
+}
+void oracle_intersect_rays(Oracle* o, const float* origins, const float* directions, int n, PtHit* out)
+{
+    intersectRays(o, origins, directions, n, out, false);
+}
+void oracle_intersect_rays_linear(Oracle* o, const float* origins, const float* directions, int n, PtHit* out)
+{
+    intersectRays(o, origins, directions, n, out, true);
+}
+
+void oracle_rng_u01(int iter, int index, int depth, int n, float* out)
+{
+    Rng r(iter, index, depth);
+    for (int i = 0; i < n; i++) out[i] = r.u01();
+}
+void oracle_hemisphere(Oracle* o, int iter, int index, int depth, const float normal[3], float out[3])
+{
+    Rng r(iter, index, depth);
+    V3 d = hemisphereCosine(o ? *o->M : kLibm, V3(normal), r);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+float oracle_math_eval(int mode, int fn, float a, float b)
+{
+    const MathFns& M = mode == ORACLE_MATH_DET ? kDet : kLibm;
+    switch (fn) {
+    case 0: return M.sin(a);
+    case 1: return M.cos(a);
+    case 2: return M.acos(a);
+    case 3: return M.atan2(a, b);
+    case 4: return M.exp(a);
+    case 5: return M.log(a);
+    case 6: return M.pow5(a);
+    case 7: return a / b;
+    case 8: return sqrtf(a);
+    default: return 0.0f;
+    }
+}
+
+int oracle_bvh_build(const PtTriangle* tris, int n, int maxDepth, PtBvhNode** nodes, int* nodeCount,
+                     int32_t** indices, int* indexCount, int* leafCount, int* maxDepthOut)
+{
+    BvhBuilder b;
+    b.build(tris, n, maxDepth);
+    *nodeCount = (int)b.nodes.size();
+    *indexCount = (int)b.indices.size();
+    *nodes = (PtBvhNode*)malloc(sizeof(PtBvhNode) * std::max<size_t>(1, b.nodes.size()));
+    *indices = (int32_t*)malloc(sizeof(int32_t) * std::max<size_t>(1, b.indices.size()));
+    memcpy(*nodes, b.nodes.data(), sizeof(PtBvhNode) * b.nodes.size());
+    memcpy(*indices, b.indices.data(), sizeof(int32_t) * b.indices.size());
+    int leaves = 0;
+    for (auto& nd : b.nodes) if (nd.leftChild == -1) leaves++;
+    if (leafCount) *leafCount = leaves;
+    if (maxDepthOut) *maxDepthOut = b.statDepth;
+    return 0;
+}
+void oracle_free(void* p) { free(p); }
+int oracle_mesh_bvh(Oracle* o, int mesh, const PtBvhNode** nodes, int* nodeCount, const int32_t** indices, int* indexCount)
+{
+    if (mesh < 0 || mesh >= (int)o->meshes.size()) return -1;
+    *nodes = o->meshes[mesh].nodes.data(); *nodeCount = (int)o->meshes[mesh].nodes.size();
+    *indices = o->meshes[mesh].indices.data(); *indexCount = (int)o->meshes[mesh].indices.size();
+    return 0;
+}
+
+} // extern "C"
