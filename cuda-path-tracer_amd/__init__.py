@@ -10,6 +10,14 @@ import os
 
 import numpy as np
 
+try:
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7; loading it first makes the
+    # dynamic linker bind libmi_pathtrace.so to that same copy (equal SONAME) instead of opening a second
+    # runtime from /opt/rocm, which cannot see the device once another runtime holds it.
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi_pathtrace.so")
 

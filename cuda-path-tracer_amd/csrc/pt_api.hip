@@ -1,0 +1,611 @@
+/*
+ * pt_api.hip — the C ABI of include/mi_pathtrace.h: context lifetime
+ * (pathtraceInit / pathtraceFree, src/pathtrace.cu:428-684), the per-iteration
+ * host loop (pathtrace, src/pathtrace.cu:2659-2930) and the parity hooks.
+ *
+ * The host loop enqueues a fixed sequence of launches per bounce on one HIP
+ * stream and never reads a count back: live-path counts stay in device memory.
+ */
+#include "pt_scene_dev.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace ptd;
+
+void pt_set_error(const char* fmt, ...);
+
+void ptl_camera(hipStream_t s, const PtCamera& cam, int iter, int depth, PathState st, uint32_t* live);
+void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, int bounce, int sortOn, bool count, void* dc);
+void ptl_sort(hipStream_t s, Queues q, int bounce, int numBuckets);
+void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, int iter, int bounce, int sortOn, bool count, void* dc);
+void ptl_compact(hipStream_t s, Queues q, int bounce, int sortOn);
+void ptl_finish(hipStream_t s, PathState st, Queues q, int depth, void* dc);
+void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
+void ptl_intersect_rays(hipStream_t s, const SceneView& S, const float* o, const float* d, int n, PtHit* out);
+void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d);
+void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, float* out);
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            pt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PT_EHIP;                                                                        \
+        }                                                                                          \
+    } while (0)
+
+enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_COUNT };
+
+struct TimedSpan { hipEvent_t a, b; int stage; };
+
+struct PtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SceneView view{};
+    PathState state{};
+    Queues queues{};
+    DevCounters* dc = nullptr;
+    PtCamera cam{};
+    int traceDepth = 8;
+    int numPixels = 0;
+    bool ownImage = true;
+    float* imageOwned = nullptr;
+    /* options */
+    int sortOn = 1, useBvh = 1, timing = 0, counters = 0;
+    /* bookkeeping */
+    std::vector<void*> allocs;
+    uint64_t iterations = 0;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> freeEvents;
+    float ms[ST_COUNT] = { 0, 0, 0, 0, 0 };
+    uint32_t launches[ST_COUNT] = { 0, 0, 0, 0, 0 };
+};
+
+namespace {
+
+template <typename T>
+int devAlloc(PtContext* c, T** out, size_t count)
+{
+    *out = nullptr;
+    if (count == 0) count = 1;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        pt_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return PT_ENOMEM;
+    }
+    c->allocs.push_back(p);
+    *out = (T*)p;
+    return PT_OK;
+}
+
+template <typename T>
+int devUpload(PtContext* c, T** out, const T* host, size_t count)
+{
+    int rc = devAlloc(c, out, count);
+    if (rc != PT_OK) return rc;
+    if (count) HIP_TRY(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+/* getGeomArea (src/pathtrace.cu:217-230) */
+float geomArea(const PtGeom& g)
+{
+    const float PI = kPI;
+    if (g.type == PT_SPHERE) { float radius = g.scale[0] * 0.5f; return 4.0f * PI * radius * radius; }
+    if (g.type == PT_CUBE) { float sx = g.scale[0], sy = g.scale[1], sz = g.scale[2]; return 2.0f * (sx * sy + sy * sz + sz * sx); }
+    return 1.0f;
+}
+
+/* luminance * sin(theta) tables: conditional CDF per row, marginal CDF over rows
+ * (buildEnvMapDistribution, src/pathtrace.cu:336-425; host arithmetic, libm sinf) */
+void buildEnvCdfs(const PtEnvMap& env, std::vector<float>& marginal, std::vector<float>& conditional, float& totalPower)
+{
+    const int W = env.width, H = env.height;
+    const float PI = kPI;
+    conditional.assign((size_t)W * H, 0.0f);
+    marginal.assign(H, 0.0f);
+    std::vector<float> rowPower(H);
+    for (int y = 0; y < H; ++y) {
+        float theta = (y + 0.5f) * PI / H;
+        float st = sinf(theta);
+        float rowSum = 0.0f;
+        for (int x = 0; x < W; ++x) {
+            const float* c = env.data + 3 * ((size_t)y * W + x);
+            float lum = 0.299f * c[0] + 0.587f * c[1] + 0.114f * c[2];
+            lum *= st;
+            rowSum += lum;
+            conditional[(size_t)y * W + x] = rowSum;
+        }
+        rowPower[y] = rowSum;
+        if (rowSum > 0) {
+            float inv = 1.0f / rowSum;
+            for (int x = 0; x < W; ++x) conditional[(size_t)y * W + x] *= inv;
+        }
+    }
+    float total = 0.0f;
+    for (int y = 0; y < H; ++y) { total += rowPower[y]; marginal[y] = total; }
+    totalPower = total;
+    if (total > 0) { float inv = 1.0f / total; for (int y = 0; y < H; ++y) marginal[y] *= inv; }
+}
+
+struct FlatMesh {
+    std::vector<float4> nodes;     /* 2 per node */
+    std::vector<float4> hot;       /* 3 per leaf-order triangle */
+    std::vector<float4> cold;      /* 4 per leaf-order triangle */
+    std::vector<int> leafOfOrig;
+    bool hasBvh = false;
+};
+
+inline float asF(int v) { float f; memcpy(&f, &v, 4); return f; }
+
+void pushTriangle(FlatMesh& fm, const PtTriangle& t, int orig)
+{
+    /* edges precomputed with the same single subtraction the test would do */
+    float e1[3], e2[3];
+    for (int k = 0; k < 3; ++k) { e1[k] = t.v1[k] - t.v0[k]; e2[k] = t.v2[k] - t.v0[k]; }
+    fm.hot.push_back(make_float4(t.v0[0], t.v0[1], t.v0[2], e1[0]));
+    fm.hot.push_back(make_float4(e1[1], e1[2], e2[0], e2[1]));
+    fm.hot.push_back(make_float4(e2[2], asF(orig), 0.0f, 0.0f));
+    fm.cold.push_back(make_float4(t.n0[0], t.n0[1], t.n0[2], t.n1[0]));
+    fm.cold.push_back(make_float4(t.n1[1], t.n1[2], t.n2[0], t.n2[1]));
+    fm.cold.push_back(make_float4(t.n2[2], t.uv0[0], t.uv0[1], t.uv1[0]));
+    fm.cold.push_back(make_float4(t.uv1[1], t.uv2[0], t.uv2[1], asF(t.materialId)));
+}
+
+/* Re-emit a host BVH (40-byte nodes + index array, src/bvh.h:55-65) in depth-first
+ * pre-order with the left child adjacent, leaf triangles contiguous in leaf order. */
+int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nnodes, const int32_t* indices, int nidx,
+                FlatMesh& fm)
+{
+    fm.leafOfOrig.assign(std::max(ntri, 1), -1);
+    if (ntri == 0 || nnodes == 0) { fm.hasBvh = false; return PT_OK; }
+    struct Item { int src; int depth; int parentSlot; };
+    std::vector<Item> work;
+    work.push_back({ 0, 0, -1 });
+    int emitted = 0;
+    int leafPos = 0;
+    while (!work.empty()) {
+        Item it = work.back();
+        work.pop_back();
+        if (it.src < 0 || it.src >= nnodes) { pt_set_error("BVH child index %d out of range", it.src); return PT_EINVAL; }
+        if (emitted >= nnodes) { pt_set_error("BVH is not a tree (node visited twice)"); return PT_EINVAL; }
+        if (it.depth >= kStackDepth) { pt_set_error("BVH deeper than %d levels is not supported", kStackDepth - 1); return PT_ELIMIT; }
+        const PtBvhNode& n = nodes[it.src];
+        int self = emitted++;
+        if (it.parentSlot >= 0) fm.nodes[2 * (size_t)it.parentSlot].w = asF(self);   /* this is the parent's right child */
+        if (n.leftChild == -1) {
+            if (n.triangleCount <= 0 || n.triangleStart < 0 || n.triangleStart + n.triangleCount > nidx) {
+                pt_set_error("BVH leaf with invalid triangle range");
+                return PT_EINVAL;
+            }
+            fm.nodes.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], asF(leafPos)));
+            fm.nodes.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], asF(n.triangleCount)));
+            for (int i = 0; i < n.triangleCount; ++i) {
+                int orig = indices[n.triangleStart + i];
+                if (orig < 0 || orig >= ntri) { pt_set_error("BVH triangle index out of range"); return PT_EINVAL; }
+                pushTriangle(fm, tris[orig], orig);
+                if (fm.leafOfOrig[orig] < 0) fm.leafOfOrig[orig] = leafPos;
+                ++leafPos;
+            }
+        } else {
+            fm.nodes.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], asF(-1)));
+            fm.nodes.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], asF(0)));
+            /* right is emitted after the whole left subtree: push right first, then left */
+            work.push_back({ n.rightChild, it.depth + 1, self });
+            work.push_back({ n.leftChild, it.depth + 1, -1 });
+        }
+    }
+    /* triangles no leaf references (possible only with a caller-supplied BVH) stay reachable
+       for the linear fallback */
+    for (int i = 0; i < ntri; ++i)
+        if (fm.leafOfOrig[i] < 0) { pushTriangle(fm, tris[i], i); fm.leafOfOrig[i] = leafPos++; }
+    fm.hasBvh = true;
+    return PT_OK;
+}
+
+hipEvent_t takeEvent(PtContext* c)
+{
+    if (!c->freeEvents.empty()) { hipEvent_t e = c->freeEvents.back(); c->freeEvents.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct SpanGuard {
+    PtContext* c; int stage; hipEvent_t a = nullptr;
+    SpanGuard(PtContext* ctx, int st) : c(ctx), stage(st)
+    {
+        c->launches[stage]++;
+        if (c->timing) { a = takeEvent(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~SpanGuard()
+    {
+        if (c->timing) { hipEvent_t b = takeEvent(c); (void)hipEventRecord(b, c->stream); c->spans.push_back({ a, b, stage }); }
+    }
+};
+
+void resolveSpans(PtContext* c)
+{
+    for (auto& s : c->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) c->ms[s.stage] += ms;
+        c->freeEvents.push_back(s.a);
+        c->freeEvents.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_destroy(PtContext* c)
+{
+    if (!c) return PT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    resolveSpans(c);
+    for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PT_OK;
+}
+
+int pt_create(const PtSceneDesc* d, int device, PtContext** out)
+{
+    if (!d || !out) { pt_set_error("pt_create: null argument"); return PT_EINVAL; }
+    *out = nullptr;
+    const int W = d->camera.resolution[0], H = d->camera.resolution[1];
+    if (W <= 0 || H <= 0 || (long long)W * H > (1ll << 30)) { pt_set_error("pt_create: bad resolution %dx%d", W, H); return PT_EINVAL; }
+    if (d->traceDepth < 1 || d->traceDepth > PT_MAX_DEPTH) { pt_set_error("pt_create: traceDepth must be in [1,%d]", PT_MAX_DEPTH); return PT_EINVAL; }
+    if (d->geomCount < 0 || d->materialCount < 1) { pt_set_error("pt_create: scene needs at least one material"); return PT_EINVAL; }
+    if (d->materialCount + 1 > kMaxBuckets) { pt_set_error("pt_create: at most %d materials are supported", kMaxBuckets - 1); return PT_ELIMIT; }
+    for (int i = 0; i < d->geomCount; ++i) {
+        const PtGeom& g = d->geoms[i];
+        if (g.type == PT_CUBE || g.type == PT_SPHERE) {
+            if (g.materialid < 0 || g.materialid >= d->materialCount) { pt_set_error("pt_create: geom %d has material id %d out of range", i, g.materialid); return PT_EINVAL; }
+        } else if (g.type == PT_GLTF_MESH) {
+            if (g.meshIndex >= d->meshCount) { pt_set_error("pt_create: geom %d references mesh %d of %d", i, g.meshIndex, d->meshCount); return PT_EINVAL; }
+        } else { pt_set_error("pt_create: geom %d has unknown type %d", i, g.type); return PT_EINVAL; }
+    }
+    for (int m = 0; m < d->meshCount; ++m)
+        for (int t = 0; t < d->meshes[m].triangleCount; ++t) {
+            int id = d->meshes[m].triangles[t].materialId;
+            if (id < 0 || id >= d->materialCount) { pt_set_error("pt_create: mesh %d triangle %d has material id %d out of range", m, t, id); return PT_EINVAL; }
+        }
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { pt_set_error("pt_create: device %d of %d", device, ndev); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(device));
+
+    PtContext* c = new PtContext();
+    c->device = device;
+    c->cam = d->camera;
+    c->traceDepth = d->traceDepth;
+    c->numPixels = W * H;
+    int rc = PT_OK;
+#define TRY_RC(x) do { rc = (x); if (rc != PT_OK) { pt_destroy(c); return rc; } } while (0)
+#define TRY_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { pt_set_error("%s failed: %s", #x, hipGetErrorString(e_)); pt_destroy(c); return PT_EHIP; } } while (0)
+    TRY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+    /* ---- meshes: concatenated in geom order (src/pathtrace.cu:483-505), one BVH per mesh (:269-334) */
+    std::vector<DGeom> geoms(d->geomCount);
+    std::vector<float4> allNodes, allHot, allCold;
+    std::vector<int> allLeafOfOrig;
+    for (int i = 0; i < d->geomCount; ++i) {
+        const PtGeom& g = d->geoms[i];
+        DGeom& G = geoms[i];
+        memset(&G, 0, sizeof(G));
+        G.type = g.type; G.materialid = g.materialid; G.meshIndex = g.meshIndex;
+        memcpy(G.T, g.transform, 64); memcpy(G.I, g.inverseTransform, 64); memcpy(G.IT, g.invTranspose, 64);
+        memcpy(G.translation, g.translation, 12); memcpy(G.scale, g.scale, 12);
+        if (g.type == PT_GLTF_MESH && g.meshIndex >= 0) {
+            const PtMesh& pm = d->meshes[g.meshIndex];
+            FlatMesh fm;
+            PtBvh* built = nullptr;
+            const PtBvhNode* nodes = pm.nodes; int nn = pm.nodeCount;
+            const int32_t* idx = pm.triangleIndices; int ni = pm.triangleIndexCount;
+            if ((!nodes || !idx) && pm.triangleCount > 0) {
+                TRY_RC(pt_bvh_build(pm.triangles, pm.triangleCount, 24 /* BVH_MAX_TREE_DEPTH, src/pathtrace.cu:194 */, &built));
+                nodes = pt_bvh_nodes(built, &nn);
+                idx = pt_bvh_indices(built, &ni);
+            }
+            rc = flattenMesh(pm.triangles, pm.triangleCount, nodes, nn, idx, ni, fm);
+            if (built) pt_bvh_free(built);
+            if (rc != PT_OK) { pt_destroy(c); return rc; }
+            G.nodeStart = (int)(allNodes.size() / 2);
+            G.triStart = (int)(allHot.size() / 3);
+            G.triCount = pm.triangleCount;
+            G.hasBvh = fm.hasBvh ? 1 : 0;
+            /* leafOfOrig is indexed by triStart + original index; keep both arrays aligned */
+            size_t ntriFlat = fm.hot.size() / 3;
+            allNodes.insert(allNodes.end(), fm.nodes.begin(), fm.nodes.end());
+            allHot.insert(allHot.end(), fm.hot.begin(), fm.hot.end());
+            allCold.insert(allCold.end(), fm.cold.begin(), fm.cold.end());
+            fm.leafOfOrig.resize(ntriFlat, 0);
+            allLeafOfOrig.insert(allLeafOfOrig.end(), fm.leafOfOrig.begin(), fm.leafOfOrig.end());
+        }
+    }
+    float4 *dNodes, *dHot, *dCold; int* dLeaf; DGeom* dGeoms; PtMaterial* dMats;
+    TRY_RC(devUpload(c, &dNodes, allNodes.data(), allNodes.size()));
+    TRY_RC(devUpload(c, &dHot, allHot.data(), allHot.size()));
+    TRY_RC(devUpload(c, &dCold, allCold.data(), allCold.size()));
+    TRY_RC(devUpload(c, &dLeaf, allLeafOfOrig.data(), allLeafOfOrig.size()));
+    TRY_RC(devUpload(c, &dGeoms, geoms.data(), geoms.size()));
+    TRY_RC(devUpload(c, &dMats, d->materials, (size_t)d->materialCount));
+
+    /* ---- textures (src/pathtrace.cu:507-537) */
+    std::vector<DTexture> tex(d->textureCount);
+    for (int t = 0; t < d->textureCount; ++t) {
+        const PtTexture& pt = d->textures[t];
+        if (!pt.data || pt.width <= 0 || pt.height <= 0 || pt.components < 1 || pt.components > 4) { pt_set_error("pt_create: texture %d is invalid", t); pt_destroy(c); return PT_EINVAL; }
+        uint8_t* dd;
+        /* +4 bytes so the 4-byte RGBA fetch of the last texel stays inside the allocation for 3-component images too */
+        TRY_RC(devAlloc(c, &dd, (size_t)pt.width * pt.height * pt.components + 4));
+        TRY_HIP(hipMemcpy(dd, pt.data, (size_t)pt.width * pt.height * pt.components, hipMemcpyHostToDevice));
+        tex[t].data = dd; tex[t].width = pt.width; tex[t].height = pt.height; tex[t].components = pt.components; tex[t].pad = 0;
+    }
+    DTexture* dTex;
+    TRY_RC(devUpload(c, &dTex, tex.data(), tex.size()));
+
+    /* ---- lights (initializeLights, src/pathtrace.cu:232-267) */
+    std::vector<DLight> lights;
+    float totalArea = 0.0f;
+    for (int i = 0; i < d->geomCount; ++i) {
+        int matId = d->geoms[i].materialid;
+        if (matId >= 0 && matId < d->materialCount && d->materials[matId].emittance > 0.0f) {
+            DLight L; L.geomIdx = i; L.area = geomArea(d->geoms[i]); L.pdf = 0.0f;
+            totalArea += L.area;
+            lights.push_back(L);
+        }
+    }
+    for (auto& L : lights) L.pdf = L.area / totalArea;
+    DLight* dLights;
+    TRY_RC(devUpload(c, &dLights, lights.data(), lights.size()));
+
+    /* ---- environment map + CDFs (src/pathtrace.cu:453-476) */
+    const bool envOn = d->env.enabled && d->env.data && d->env.width > 0 && d->env.height > 0;
+    float* dEnv = nullptr; float* dMarg = nullptr; float* dCond = nullptr; float totalPower = 0.0f;
+    if (envOn) {
+        std::vector<float> marg, cond;
+        buildEnvCdfs(d->env, marg, cond, totalPower);
+        TRY_RC(devUpload(c, &dEnv, d->env.data, (size_t)d->env.width * d->env.height * 3));
+        TRY_RC(devUpload(c, &dMarg, marg.data(), marg.size()));
+        TRY_RC(devUpload(c, &dCond, cond.data(), cond.size()));
+    }
+
+    SceneView& V = c->view;
+    V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.leafOfOrig = dLeaf;
+    V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond;
+    V.numGeoms = d->geomCount; V.numMaterials = d->materialCount; V.numTextures = d->textureCount; V.numLights = (int)lights.size();
+    V.envWidth = envOn ? d->env.width : 0; V.envHeight = envOn ? d->env.height : 0; V.envEnabled = envOn ? 1 : 0; V.useBvh = 1;
+    V.envTotalPower = totalPower;
+    V.numBuckets = d->materialCount + 1;
+
+    /* ---- path state, queues, image */
+    const size_t N = (size_t)c->numPixels;
+    PathState& P = c->state;
+    TRY_RC(devAlloc(c, &P.rayO, N)); TRY_RC(devAlloc(c, &P.rayD, N)); TRY_RC(devAlloc(c, &P.col, N));
+    TRY_RC(devAlloc(c, &P.hitA, N)); TRY_RC(devAlloc(c, &P.hitB, N));
+    TRY_RC(devAlloc(c, &c->imageOwned, N * 3));
+    P.image = c->imageOwned;
+    TRY_HIP(hipMemset(P.image, 0, N * 3 * sizeof(float)));
+    Queues& Q = c->queues;
+    Q.numBlocks = (int)((N + kBlock - 1) / kBlock);
+    TRY_RC(devAlloc(c, &Q.q0, N)); TRY_RC(devAlloc(c, &Q.q1, N)); TRY_RC(devAlloc(c, &Q.keys, N));
+    TRY_RC(devAlloc(c, &Q.blockHist, (size_t)V.numBuckets * Q.numBlocks));
+    TRY_RC(devAlloc(c, &Q.blockAlive, (size_t)Q.numBlocks));
+    TRY_RC(devAlloc(c, &Q.live, (size_t)PT_MAX_DEPTH + 2));
+    TRY_HIP(hipMemset(Q.live, 0, (PT_MAX_DEPTH + 2) * sizeof(uint32_t)));
+    TRY_RC(devAlloc(c, &c->dc, 1));
+    TRY_HIP(hipMemset(c->dc, 0, sizeof(DevCounters)));
+    TRY_HIP(hipDeviceSynchronize());
+#undef TRY_RC
+#undef TRY_HIP
+    *out = c;
+    return PT_OK;
+}
+
+int pt_trace(PtContext* c, int iter)
+{
+    if (!c) { pt_set_error("pt_trace: null context"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    SceneView V = c->view;
+    V.useBvh = c->useBvh;
+    const bool count = c->counters != 0;
+    { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, iter, c->traceDepth, c->state, c->queues.live); }
+    for (int b = 0; b < c->traceDepth; ++b) {
+        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, b, c->sortOn, count, c->dc); }
+        if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, b, V.numBuckets); }
+        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, iter, b, c->sortOn, count, c->dc); }
+        { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, b, c->sortOn); }
+    }
+    ptl_finish(s, c->state, c->queues, c->traceDepth, c->dc);
+    HIP_TRY(hipGetLastError());
+    c->iterations++;
+    return PT_OK;
+}
+
+int pt_trace_range(PtContext* c, int iter_begin, int iter_end, int iter_stride)
+{
+    if (!c || iter_stride <= 0) { pt_set_error("pt_trace_range: bad argument"); return PT_EINVAL; }
+    for (int it = iter_begin; it < iter_end; it += iter_stride) {
+        int rc = pt_trace(c, it);
+        if (rc != PT_OK) return rc;
+    }
+    return PT_OK;
+}
+
+int pt_sync(PtContext* c)
+{
+    if (!c) { pt_set_error("pt_sync: null context"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    resolveSpans(c);
+    return PT_OK;
+}
+
+int pt_display(PtContext* c, int iter, uint8_t* dev_rgba)
+{
+    if (!c || !dev_rgba || iter <= 0) { pt_set_error("pt_display: bad argument"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    ptl_display(c->stream, c->state.image, c->numPixels, iter, dev_rgba);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_download(PtContext* c, float* host_rgb)
+{
+    if (!c || !host_rgb) { pt_set_error("pt_download: null argument"); return PT_EINVAL; }
+    int rc = pt_sync(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemcpy(host_rgb, c->state.image, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_bind_image(PtContext* c, float* dev_rgb)
+{
+    if (!c) { pt_set_error("pt_bind_image: null context"); return PT_EINVAL; }
+    int rc = pt_sync(c);
+    if (rc != PT_OK) return rc;
+    c->state.image = dev_rgb ? dev_rgb : c->imageOwned;
+    c->ownImage = dev_rgb == nullptr;
+    return PT_OK;
+}
+
+int pt_upload_image(PtContext* c, const float* host_rgb)
+{
+    if (!c || !host_rgb) { pt_set_error("pt_upload_image: null argument"); return PT_EINVAL; }
+    int rc = pt_sync(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemcpy(c->state.image, host_rgb, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+int pt_clear(PtContext* c)
+{
+    if (!c) { pt_set_error("pt_clear: null context"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->state.image, 0, (size_t)c->numPixels * 3 * sizeof(float), c->stream));
+    return PT_OK;
+}
+
+int pt_set_option(PtContext* c, int option, int value)
+{
+    if (!c) { pt_set_error("pt_set_option: null context"); return PT_EINVAL; }
+    switch (option) {
+    case PT_OPT_MATERIAL_SORT: c->sortOn = value ? 1 : 0; break;
+    case PT_OPT_USE_BVH: c->useBvh = value ? 1 : 0; break;
+    case PT_OPT_STAGE_TIMING: { int rc = pt_sync(c); if (rc != PT_OK) return rc; c->timing = value ? 1 : 0; break; }
+    case PT_OPT_COUNTERS: c->counters = value ? 1 : 0; break;
+    case PT_OPT_USE_GRAPH: break;      /* accepted; launches are always direct in this build */
+    default: pt_set_error("pt_set_option: unknown option %d", option); return PT_EINVAL;
+    }
+    return PT_OK;
+}
+
+int pt_stats(PtContext* c, PtStats* out)
+{
+    if (!c || !out) { pt_set_error("pt_stats: null argument"); return PT_EINVAL; }
+    int rc = pt_sync(c);
+    if (rc != PT_OK) return rc;
+    DevCounters h;
+    HIP_TRY(hipMemcpy(&h, c->dc, sizeof(h), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->pathBounces = h.pathBounces;
+    out->iterations = c->iterations;
+    /* bounces executed: the reference leaves its loop when no path is left or depth is reached */
+    uint32_t depth = (uint32_t)c->traceDepth;
+    for (int b = 0; b <= c->traceDepth && b < PT_MAX_DEPTH; ++b) out->lastLive[b] = h.lastLive[b];
+    for (int b = 1; b <= c->traceDepth; ++b) if (h.lastLive[b] == 0) { depth = (uint32_t)b; break; }
+    out->lastDepth = c->iterations ? depth : 0;
+    out->nodesVisited = h.nodes; out->trisTested = h.tris; out->meshHits = h.meshHits;
+    out->msCamera = c->ms[ST_CAMERA]; out->msIntersect = c->ms[ST_INTERSECT]; out->msSort = c->ms[ST_SORT];
+    out->msShade = c->ms[ST_SHADE]; out->msCompact = c->ms[ST_COMPACT];
+    out->launchesIntersect = c->launches[ST_INTERSECT]; out->launchesShade = c->launches[ST_SHADE];
+    return PT_OK;
+}
+
+int pt_reset_stats(PtContext* c)
+{
+    if (!c) { pt_set_error("pt_reset_stats: null context"); return PT_EINVAL; }
+    int rc = pt_sync(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemset(c->dc, 0, sizeof(DevCounters)));
+    c->iterations = 0;
+    for (int i = 0; i < ST_COUNT; ++i) { c->ms[i] = 0.0f; c->launches[i] = 0; }
+    return PT_OK;
+}
+
+void* pt_stream(PtContext* c) { return c ? (void*)c->stream : nullptr; }
+
+int pt_intersect_rays(PtContext* c, const float* origins, const float* directions, int n, PtHit* out)
+{
+    if (!c || n < 0 || (n > 0 && (!origins || !directions || !out))) { pt_set_error("pt_intersect_rays: bad argument"); return PT_EINVAL; }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    float *dO = nullptr, *dD = nullptr; PtHit* dH = nullptr;
+    HIP_TRY(hipMalloc((void**)&dO, (size_t)n * 12));
+    hipError_t e1 = hipMalloc((void**)&dD, (size_t)n * 12);
+    hipError_t e2 = hipMalloc((void**)&dH, (size_t)n * sizeof(PtHit));
+    int rc = PT_OK;
+    if (e1 != hipSuccess || e2 != hipSuccess) { pt_set_error("pt_intersect_rays: out of device memory"); rc = PT_ENOMEM; }
+    if (rc == PT_OK) {
+        SceneView V = c->view;
+        V.useBvh = c->useBvh;
+        hipError_t e = hipMemcpyAsync(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dD, directions, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) { ptl_intersect_rays(c->stream, V, dO, dD, n, dH); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dH, (size_t)n * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); rc = PT_EHIP; }
+    }
+    (void)hipFree(dO); if (dD) (void)hipFree(dD); if (dH) (void)hipFree(dH);
+    return rc;
+}
+
+int pt_camera_rays(PtContext* c, int iter, float* origins, float* directions)
+{
+    if (!c || !origins || !directions) { pt_set_error("pt_camera_rays: null argument"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->numPixels;
+    float *dO = nullptr, *dD = nullptr;
+    HIP_TRY(hipMalloc((void**)&dO, (size_t)n * 12));
+    if (hipMalloc((void**)&dD, (size_t)n * 12) != hipSuccess) { (void)hipFree(dO); pt_set_error("pt_camera_rays: out of device memory"); return PT_ENOMEM; }
+    ptl_camera(c->stream, c->cam, iter, c->traceDepth, c->state, c->queues.live);
+    ptl_export_rays(c->stream, c->state, n, dO, dD);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(origins, dO, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(directions, dD, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dO); (void)hipFree(dD);
+    if (e != hipSuccess) { pt_set_error("pt_camera_rays: %s", hipGetErrorString(e)); return PT_EHIP; }
+    return PT_OK;
+}
+
+int pt_math_eval(int device, int fn, const float* a, const float* b, int n, float* out)
+{
+    if (!a || !out || n < 0) { pt_set_error("pt_math_eval: bad argument"); return PT_EINVAL; }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(device));
+    float *dA = nullptr, *dB = nullptr, *dR = nullptr;
+    HIP_TRY(hipMalloc((void**)&dA, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&dR, (size_t)n * 4));
+    if (b) HIP_TRY(hipMalloc((void**)&dB, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(dA, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (b) HIP_TRY(hipMemcpy(dB, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    ptl_math(nullptr, fn, dA, dB, n, dR);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dR, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dR); if (dB) (void)hipFree(dB);
+    return PT_OK;
+}
+
+} // extern "C"

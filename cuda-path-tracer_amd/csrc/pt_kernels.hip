@@ -1,0 +1,457 @@
+/*
+ * pt_kernels.hip — gfx950 kernels of the wavefront loop and their launchers.
+ *
+ * One iteration (= one sample per pixel) runs, per bounce b:
+ *   k_intersect      closest hit for queue slots [0, live[b]); writes the hit record by
+ *                    pixel, the sort bucket by slot, and this workgroup's bucket histogram
+ *   k_sort_scan      exclusive scan of the (bucket-major, workgroup-minor) histogram
+ *   k_sort_scatter   stable counting sort of the 4-byte pixel queue by material bucket
+ *   k_shade          shades slot i = sorted position (the index the RNG is seeded with),
+ *                    adds terminated paths to the image, flags survivors in the queue
+ *   k_compact_scan / k_compact_scatter   order-preserving compaction of the queue
+ * All launches use a fixed grid and read the live count from device memory, so the host
+ * never waits for a count (the reference synchronises >= 5 times per bounce,
+ * src/pathtrace.cu:2729-2879).
+ *
+ * Wave64 throughout: ranks come from 64-bit ballots + popcount, block-level carries
+ * go through LDS, the per-ray traversal stack is a [32][256] LDS array (one conflict-free
+ * column per lane).
+ */
+#include "pt_scene_dev.h"
+
+namespace ptd {
+
+PT_DEV int laneId() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+PT_DEV unsigned long long laneMaskLt() { return (1ull << laneId()) - 1ull; }
+
+PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc)
+{
+    /* one atomic per wave and counter */
+    unsigned n = c.nodes, t = c.tris, h = c.meshHits;
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off);
+        t += __shfl_down(t, off);
+        h += __shfl_down(h, off);
+    }
+    if (laneId() == 0) {
+        if (n) atomicAdd(&dc->nodes, (unsigned long long)n);
+        if (t) atomicAdd(&dc->tris, (unsigned long long)t);
+        if (h) atomicAdd(&dc->meshHits, (unsigned long long)h);
+    }
+}
+
+/* ------------------------------------------------------------------ camera
+ * One thread per pixel: 2x2 stratified jitter cell = iter % 4, two draws from the
+ * (iter, pixel, 0) stream, pinhole direction (generateRayFromCamera,
+ * src/pathtrace.cu:694-745). */
+__global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, int iter, int traceDepth, PathState st, uint32_t* live)
+{
+    const int W = cam.resolution[0], H = cam.resolution[1];
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index == 0) live[0] = (uint32_t)(W * H);
+    if (index >= W * H) return;
+    const int x = index % W, y = index / W;
+    Lcg rng;
+    rng.seed(iter, index, 0);
+    const int cell = iter % 4;
+    const int cellX = cell % 2, cellY = cell / 2;
+    const float cellSize = 1.0f / 2.0f;
+    float jx = (cellX + rng.u01()) * cellSize;
+    float jy = (cellY + rng.u01()) * cellSize;
+    float px = (float)x + jx - 0.5f;
+    float py = (float)y + jy - 0.5f;
+    F3 dir = normalize(f3(cam.view) - f3(cam.right) * cam.pixelLength[0] * (px - (float)W * 0.5f)
+                       - f3(cam.up) * cam.pixelLength[1] * (py - (float)H * 0.5f));
+    st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
+    st.rayD[index] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
+}
+
+/* --------------------------------------------------------------- intersect */
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_intersect(SceneView S, PathState st, Queues q, int bounce, int sortOn, DevCounters* dc)
+{
+    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_hist[kMaxBuckets];
+    const int tid = threadIdx.x;
+    const uint32_t n = q.live[bounce];
+    const int slot = blockIdx.x * kBlock + tid;
+    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;      /* whole workgroup beyond the live range */
+
+    const int nb = S.numBuckets;
+    if (sortOn) {
+        for (int i = tid; i < nb; i += kBlock) s_hist[i] = 0;
+        __syncthreads();
+    }
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    const bool active = (uint32_t)slot < n;
+    int key = 0;
+    if (active) {
+        const int pix = bounce == 0 ? slot : q.q0[slot];
+        float4 o = st.rayO[pix], d = st.rayD[pix];
+        Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+        Hit h = closestHit<COUNT>(S, r, s_stack + tid, cnt);
+        st.hitA[pix] = make_float4(h.t, h.n.x, h.n.y, h.n.z);
+        st.hitB[pix] = make_float4(__int_as_float(h.mat), h.uv.x, h.uv.y, __int_as_float(h.geom));
+        /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */
+        key = (h.t > 0.0f) ? h.mat : (nb - 1);
+        if (sortOn) q.keys[slot] = key;
+    }
+    if (COUNT) flushCounters(cnt, dc);
+    if (sortOn) {
+        /* wave-aggregated histogram: one LDS atomic per distinct bucket per wave */
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            int leader = __builtin_ctzll(todo);
+            int k = __shfl(key, leader);
+            unsigned long long m = __ballot(active && key == k);
+            if (laneId() == leader) atomicAdd(&s_hist[k], (int)__builtin_popcountll(m));
+            todo &= ~m;
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += kBlock) q.blockHist[(size_t)i * q.numBlocks + blockIdx.x] = s_hist[i];
+    }
+}
+
+/* block-wide exclusive scan helper for 1024 threads; returns the exclusive prefix of v and the
+ * block total through *total */
+PT_DEV int blockExclusiveScan1024(int v, int* s_wave, int* total)
+{
+    const int lane = laneId(), wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < 16 ? s_wave[lane] : 0;
+        int winc = w;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            int t = __shfl_up(winc, off);
+            if (lane >= off) winc += t;
+        }
+        if (lane < 16) s_wave[lane] = winc - w;          /* exclusive wave offsets */
+        if (lane == 15) s_wave[16] = winc;
+    }
+    __syncthreads();
+    int res = s_wave[wave] + inc - v;
+    *total = s_wave[16];
+    __syncthreads();
+    return res;
+}
+
+/* exclusive scan over the histogram in (bucket, workgroup) order, restricted to the
+ * workgroups that held live slots; single workgroup of 1024 threads */
+__global__ void __launch_bounds__(1024) k_sort_scan(Queues q, int bounce, int numBuckets)
+{
+    __shared__ int s_wave[17];
+    const uint32_t n = q.live[bounce];
+    if (n == 0) return;
+    const int nbAct = (int)((n + kBlock - 1) / kBlock);
+    const int total = numBuckets * nbAct;
+    int carry = 0;
+    for (int base = 0; base < total; base += 1024 * 4) {
+        int idx[4], v[4];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int i = base + threadIdx.x * 4 + k;
+            int val = 0, pos = -1;
+            if (i < total) {
+                int bucket = i / nbAct, blk = i - bucket * nbAct;
+                pos = bucket * q.numBlocks + blk;
+                val = q.blockHist[pos];
+            }
+            idx[k] = pos; v[k] = val; sum += val;
+        }
+        int blockTotal;
+        int excl = blockExclusiveScan1024(sum, s_wave, &blockTotal) + carry;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (idx[k] >= 0) q.blockHist[idx[k]] = excl;
+            excl += v[k];
+        }
+        carry += blockTotal;
+    }
+}
+
+/* stable scatter: rank inside the wave by ballot, wave offsets through LDS, workgroup
+ * offsets from the scanned histogram */
+__global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, int numBuckets)
+{
+    __shared__ int s_waveCnt[(kBlock / 64) * kMaxBuckets];
+    const int tid = threadIdx.x;
+    const uint32_t n = q.live[bounce];
+    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
+    const int slot = blockIdx.x * kBlock + tid;
+    const int wave = tid >> 6, lane = laneId();
+    for (int i = tid; i < (kBlock / 64) * numBuckets; i += kBlock) s_waveCnt[i] = 0;
+    __syncthreads();
+    const bool active = (uint32_t)slot < n;
+    int key = active ? q.keys[slot] : 0;
+    int pix = active ? (bounce == 0 ? slot : q.q0[slot]) : 0;
+    int rank = 0;
+    unsigned long long todo = __ballot(active);
+    const unsigned long long lt = laneMaskLt();
+    while (todo) {
+        int leader = __builtin_ctzll(todo);
+        int k = __shfl(key, leader);
+        unsigned long long m = __ballot(active && key == k);
+        if (active && key == k) rank = (int)__builtin_popcountll(m & lt);
+        if (lane == leader) s_waveCnt[wave * numBuckets + k] = (int)__builtin_popcountll(m);
+        todo &= ~m;
+    }
+    __syncthreads();
+    if (active) {
+        int base = q.blockHist[(size_t)key * q.numBlocks + blockIdx.x];
+        for (int w = 0; w < wave; ++w) base += s_waveCnt[w * numBuckets + key];
+        q.q1[base + rank] = pix;
+    }
+}
+
+/* ------------------------------------------------------------------- shade */
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Queues q, int iter, int bounce, int sortOn, DevCounters* dc)
+{
+    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_alive[kBlock / 64];
+    const int tid = threadIdx.x;
+    const uint32_t n = q.live[bounce];
+    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
+    const int slot = blockIdx.x * kBlock + tid;
+    const bool active = (uint32_t)slot < n;
+    int* queue = sortOn ? q.q1 : q.q0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    bool alive = false;
+    if (active) {
+        const int pix = (!sortOn && bounce == 0) ? slot : queue[slot];
+        float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
+        float4 ha = st.hitA[pix], hb = st.hitB[pix];
+        Path p;
+        p.o = f3(o.x, o.y, o.z); p.d = f3(d.x, d.y, d.z); p.color = f3(c.x, c.y, c.z);
+        p.remaining = __float_as_int(c.w);
+        p.prevSpecular = __float_as_int(o.w) != 0;
+        F2 uv; uv.x = hb.y; uv.y = hb.z;
+        shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0,
+                         s_stack + tid, cnt);
+        alive = p.remaining > 0;
+        if (alive) {
+            st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
+            st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, 0.0f);
+            st.col[pix] = make_float4(p.color.x, p.color.y, p.color.z, __int_as_float(p.remaining));
+        } else if (p.remaining == 0) {
+            /* gatherTerminatedPaths (src/pathtrace.cu:2641-2653): one path per pixel, so a plain add */
+            float* im = st.image + 3 * (size_t)pix;
+            im[0] += p.color.x; im[1] += p.color.y; im[2] += p.color.z;
+        }
+        queue[slot] = alive ? pix : (-1 - pix);
+    }
+    if (COUNT) flushCounters(cnt, dc);
+    unsigned long long m = __ballot(alive);
+    if (laneId() == 0) s_alive[tid >> 6] = (int)__builtin_popcountll(m);
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += s_alive[w];
+        q.blockAlive[blockIdx.x] = s;
+    }
+}
+
+/* exclusive scan of survivors per workgroup; publishes live[bounce + 1] */
+__global__ void __launch_bounds__(1024) k_compact_scan(Queues q, int bounce)
+{
+    __shared__ int s_wave[17];
+    const uint32_t n = q.live[bounce];
+    const int nbAct = (int)((n + kBlock - 1) / kBlock);
+    int carry = 0;
+    for (int base = 0; base < nbAct; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = i < nbAct ? q.blockAlive[i] : 0;
+        int blockTotal;
+        int excl = blockExclusiveScan1024(v, s_wave, &blockTotal) + carry;
+        if (i < nbAct) q.blockAlive[i] = excl;
+        carry += blockTotal;
+    }
+    if (threadIdx.x == 0) q.live[bounce + 1] = (uint32_t)carry;
+}
+
+/* order-preserving compaction of the flagged queue into q0 (the role thrust::remove_if plays at
+ * src/pathtrace.cu:2865-2868; a 64-lane ballot scan instead of a multi-launch Blelloch scan) */
+__global__ void __launch_bounds__(kBlock) k_compact_scatter(Queues q, int bounce, int sortOn)
+{
+    __shared__ int s_cnt[kBlock / 64];
+    const int tid = threadIdx.x;
+    const uint32_t n = q.live[bounce];
+    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
+    const int slot = blockIdx.x * kBlock + tid;
+    const int* src = sortOn ? q.q1 : q.q0;
+    int* dst = sortOn ? q.q0 : q.q1;
+    int e = ((uint32_t)slot < n) ? src[slot] : -1;
+    bool alive = e >= 0;
+    unsigned long long m = __ballot(alive);
+    int rank = (int)__builtin_popcountll(m & laneMaskLt());
+    if (laneId() == 0) s_cnt[tid >> 6] = (int)__builtin_popcountll(m);
+    __syncthreads();
+    int base = q.blockAlive[blockIdx.x];
+    for (int w = 0; w < (tid >> 6); ++w) base += s_cnt[w];
+    if (alive) dst[base + rank] = e;
+}
+
+/* unsorted mode compacts q0 -> q1; copy back so q0 is always the input of the next bounce */
+__global__ void __launch_bounds__(kBlock) k_copy_queue(Queues q, int bounce)
+{
+    const uint32_t n = q.live[bounce + 1];
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    if ((uint32_t)slot < n) q.q0[slot] = q.q1[slot];
+}
+
+/* finalGather (src/pathtrace.cu:2630-2639): survivors of the last bounce, normally none */
+__global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q, int depth)
+{
+    const uint32_t n = q.live[depth];
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    if ((uint32_t)slot >= n) return;
+    const int pix = q.q0[slot];
+    float4 c = st.col[pix];
+    float* im = st.image + 3 * (size_t)pix;
+    im[0] += c.x; im[1] += c.y; im[2] += c.z;
+}
+
+/* per-iteration bookkeeping: path-bounce total and a snapshot of the live curve */
+__global__ void k_finish(Queues q, int depth, DevCounters* dc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long s = 0;
+    for (int b = 0; b < depth; ++b) {
+        uint32_t v = q.live[b];
+        dc->lastLive[b] = v;
+        s += v;
+        if (v == 0) { for (int k = b + 1; k <= depth; ++k) dc->lastLive[k] = 0; break; }
+    }
+    dc->lastLive[depth] = q.live[depth];
+    dc->pathBounces += s;
+}
+
+/* sendImageToPBO (src/pathtrace.cu:145-166): (int)(sum / iter * 255.0) with a double 255.0 */
+__global__ void __launch_bounds__(kBlock) k_display(const float* image, int n, int iter, uint8_t* rgba)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int v = (int)(image[3 * (size_t)i + k] / iter * 255.0);
+        c[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+    uchar4 px; px.x = (unsigned char)c[0]; px.y = (unsigned char)c[1]; px.z = (unsigned char)c[2]; px.w = 0;
+    reinterpret_cast<uchar4*>(rgba)[i] = px;
+}
+
+/* parity hook: closest hit of arbitrary rays through the intersect stage's device code */
+__global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneView S, const float* o, const float* d, int n, PtHit* out)
+{
+    __shared__ int s_stack[kStackDepth * kBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = f3(o + 3 * (size_t)i); r.d = f3(d + 3 * (size_t)i);
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    Hit h = closestHit<false>(S, r, s_stack + threadIdx.x, cnt);
+    PtHit ph;
+    ph.t = h.t; ph.geom = h.geom; ph.triangle = h.tri; ph.materialId = h.t > 0.0f ? h.mat : -1;
+    ph.normal[0] = h.n.x; ph.normal[1] = h.n.y; ph.normal[2] = h.n.z;
+    ph.uv[0] = h.uv.x; ph.uv[1] = h.uv.y;
+    out[i] = ph;
+}
+
+__global__ void __launch_bounds__(kBlock) k_export_rays(PathState st, int n, float* o, float* d)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 a = st.rayO[i], b = st.rayD[i];
+    o[3 * (size_t)i] = a.x; o[3 * (size_t)i + 1] = a.y; o[3 * (size_t)i + 2] = a.z;
+    d[3 * (size_t)i] = b.x; d[3 * (size_t)i + 1] = b.y; d[3 * (size_t)i + 2] = b.z;
+}
+
+__global__ void __launch_bounds__(kBlock) k_math(int fn, const float* a, const float* b, int n, float* out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+    switch (fn) {
+    case 0: r = dm::sin(x); break;
+    case 1: r = dm::cos(x); break;
+    case 2: r = dm::acos(x); break;
+    case 3: r = dm::atan2(x, y); break;
+    case 4: r = dm::exp(x); break;
+    case 5: r = dm::log(x); break;
+    case 6: r = dm::pow5(x); break;
+    case 7: r = x / y; break;
+    case 8: r = __builtin_sqrtf(x); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+} // namespace ptd
+
+/* ---------------------------------------------------------------- launchers
+ * Plain functions so that the API translation unit stays free of kernel syntax. */
+using namespace ptd;
+
+static inline int gridFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+extern "C++" {
+
+void ptl_camera(hipStream_t s, const PtCamera& cam, int iter, int depth, PathState st, uint32_t* live)
+{
+    hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1])), dim3(kBlock), 0, s, cam, iter, depth, st, live);
+}
+void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, int bounce, int sortOn, bool count, void* dc)
+{
+    if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_intersect<false>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+}
+void ptl_sort(hipStream_t s, Queues q, int bounce, int numBuckets)
+{
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, q, bounce, numBuckets);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks), dim3(kBlock), 0, s, q, bounce, numBuckets);
+}
+void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, int iter, int bounce, int sortOn, bool count, void* dc)
+{
+    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, iter, bounce, sortOn, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, iter, bounce, sortOn, (DevCounters*)dc);
+}
+void ptl_compact(hipStream_t s, Queues q, int bounce, int sortOn)
+{
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, q, bounce);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(q.numBlocks), dim3(kBlock), 0, s, q, bounce, sortOn);
+    if (!sortOn) hipLaunchKernelGGL(k_copy_queue, dim3(q.numBlocks), dim3(kBlock), 0, s, q, bounce);
+}
+void ptl_finish(hipStream_t s, PathState st, Queues q, int depth, void* dc)
+{
+    hipLaunchKernelGGL(k_final_gather, dim3(q.numBlocks), dim3(kBlock), 0, s, st, q, depth);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, (DevCounters*)dc);
+}
+void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba)
+{
+    hipLaunchKernelGGL(k_display, dim3(gridFor(n)), dim3(kBlock), 0, s, image, n, iter, rgba);
+}
+void ptl_intersect_rays(hipStream_t s, const SceneView& S, const float* o, const float* d, int n, PtHit* out)
+{
+    hipLaunchKernelGGL(k_intersect_rays, dim3(gridFor(n)), dim3(kBlock), 0, s, S, o, d, n, out);
+}
+void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d)
+{
+    hipLaunchKernelGGL(k_export_rays, dim3(gridFor(n)), dim3(kBlock), 0, s, st, n, o, d);
+}
+void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, float* out)
+{
+    hipLaunchKernelGGL(k_math, dim3(gridFor(n)), dim3(kBlock), 0, s, fn, a, b, n, out);
+}
+
+} // extern "C++"

@@ -1,0 +1,959 @@
+/*
+ * pt_scene_dev.h — device-resident scene and path-state layouts (HBM) and the
+ * closest-hit / shading device functions shared by the kernels.
+ *
+ * Layout decisions (all arrays live in HBM for the lifetime of the context):
+ *   path state   SoA indexed by PIXEL, three 16-byte records per path
+ *                  rayO = (origin.xyz, prevIsSpecular as int bits)
+ *                  rayD = (direction.xyz, unused)
+ *                  col  = (throughput.rgb, remainingBounces as int bits)
+ *                and two 16-byte hit records
+ *                  hitA = (t, normal.xyz)     hitB = (materialId bits, u, v, geom bits)
+ *                The wavefront queue holds 4-byte pixel indices only; sorting by
+ *                material and compaction permute that queue, never the 80 bytes of
+ *                state.  A queue slot index plays the role of the array index the
+ *                reference seeds its RNG with (src/pathtrace.cu:2483-2484).
+ *   BVH nodes    32 bytes, two float4:  (bmin.xyz, a) (bmax.xyz, b)
+ *                  inner: a = right child, b = 0   (left child is node+1: pre-order)
+ *                  leaf : a = first triangle (leaf order), b = count > 0
+ *   triangles    stored in LEAF ORDER so a leaf's triangles are contiguous:
+ *                  hot  48 bytes: (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig index, -, -)
+ *                  cold 64 bytes: n0 n1 n2 uv0 uv1 uv2 materialId (fetched once per hit)
+ */
+#pragma once
+#include "../../include/mi_pathtrace.h"
+#include "pt_device.h"
+
+namespace ptd {
+
+constexpr int kBlock = 256;          /* threads per workgroup of every 1-D kernel (4 waves) */
+constexpr int kStackDepth = 32;      /* per-ray traversal stack entries held in LDS          */
+constexpr int kMaxBuckets = 256;     /* material ids + the miss bucket handled by the sort   */
+
+struct DGeom {
+    int type, materialid, nodeStart, triStart;
+    int triCount, hasBvh, meshIndex, pad0;
+    float T[16], I[16], IT[16];
+    float translation[3], pad1;
+    float scale[3], pad2;
+};
+static_assert(sizeof(DGeom) == 256, "DGeom layout");
+
+struct DTexture { const uint8_t* data; int width, height, components, pad; };
+struct DLight { int geomIdx; float area; float pdf; };
+
+struct SceneView {
+    const DGeom* geoms;
+    const PtMaterial* materials;
+    const float4* nodes;
+    const float4* triHot;
+    const float4* triCold;
+    const int* leafOfOrig;
+    const DTexture* textures;
+    const DLight* lights;
+    const float* envData;
+    const float* envMarginal;
+    const float* envConditional;
+    int numGeoms, numMaterials, numTextures, numLights;
+    int envWidth, envHeight, envEnabled, useBvh;
+    float envTotalPower;
+    int numBuckets;                 /* numMaterials + 1 */
+};
+
+struct PathState {
+    float4* rayO;
+    float4* rayD;
+    float4* col;
+    float4* hitA;
+    float4* hitB;
+    float* image;                   /* W*H*3 running sum */
+};
+
+struct Queues {
+    int* q0;            /* compacted queue (input of a bounce)                          */
+    int* q1;            /* material-sorted queue (input of shade)                        */
+    int* keys;          /* bucket per slot of q0                                         */
+    int* blockHist;     /* [numBuckets][numBlocks] histogram, scanned in place           */
+    int* blockAlive;    /* [numBlocks] survivors per workgroup, scanned in place         */
+    uint32_t* live;     /* [PT_MAX_DEPTH + 2] live paths entering bounce b               */
+    int numBlocks;      /* ceil(N / kBlock)                                              */
+};
+
+struct DevCounters {
+    unsigned long long pathBounces, nodes, tris, meshHits;
+    uint32_t lastLive[PT_MAX_DEPTH + 2];
+};
+
+struct TravCounters { uint32_t nodes, tris, meshHits; };
+
+constexpr float kPI = 3.1415926535897932384626422832795028841971f;
+constexpr float kTWO_PI = 6.2831853071795864769252867665590057683943f;
+constexpr float kSQRT_OF_ONE_THIRD = 0.5773502691896257645091487805019574556476f;
+
+struct Ray { F3 o, d; };
+struct Hit { float t; F3 n; int mat; F2 uv; int geom; int tri; };
+
+/* ------------------------------------------------------------- primitives */
+
+PT_DEV F3 pointOnRay(F3 o, F3 d, float t) { return o + (t - .0001f) * normalize(d); }
+
+/* unit cube, slab test in object space; semantics of boxIntersectionTest
+ * (src/intersections.cu:4-58): no parallel-axis guard, entry or exit face,
+ * hit point pulled back 1e-4, world distance returned */
+PT_DEV float hitBox(const DGeom& g, const Ray& r, F3& N)
+{
+    F3 qo = mulMV(g.I, r.o, 1.0f);
+    F3 qd = normalize(mulMV(g.I, r.d, 0.0f));
+    float tmin = -1e38f, tmax = 1e38f;
+    int nminAxis = -1, nmaxAxis = -1;
+    float nminSign = 0.0f, nmaxSign = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float d = comp(qd, a), o = comp(qo, a);
+        float t1 = (-0.5f - o) / d;
+        float t2 = (+0.5f - o) / d;
+        float ta = selMin(t1, t2);
+        float tb = selMax(t1, t2);
+        float s = t2 < t1 ? +1.0f : -1.0f;
+        if (ta > 0 && ta > tmin) { tmin = ta; nminAxis = a; nminSign = s; }
+        if (tb < tmax) { tmax = tb; nmaxAxis = a; nmaxSign = s; }
+    }
+    if (tmax >= tmin && tmax > 0) {
+        if (tmin <= 0) { tmin = tmax; nminAxis = nmaxAxis; nminSign = nmaxSign; }
+        F3 n = f3(nminAxis == 0 ? nminSign : 0.0f, nminAxis == 1 ? nminSign : 0.0f, nminAxis == 2 ? nminSign : 0.0f);
+        F3 P = mulMV(g.T, pointOnRay(qo, qd, tmin), 1.0f);
+        N = normalize(mulMV(g.IT, n, 0.0f));
+        return length(r.o - P);
+    }
+    return -1.0f;
+}
+
+/* radius-0.5 sphere in object space (src/intersections.cu:60-114) */
+PT_DEV float hitSphere(const DGeom& g, const Ray& r, F3& N)
+{
+    F3 ro = mulMV(g.I, r.o, 1.0f);
+    F3 rd = normalize(mulMV(g.I, r.d, 0.0f));
+    float vd = dot(ro, rd);
+    float radicand = vd * vd - (dot(ro, ro) - 0.25f);
+    if (radicand < 0) return -1.0f;
+    float sq = __builtin_sqrtf(radicand);
+    float first = -vd;
+    float t1 = first + sq;
+    float t2 = first - sq;
+    float t;
+    bool outside;
+    if (t1 < 0 && t2 < 0) return -1.0f;
+    else if (t1 > 0 && t2 > 0) { t = nanMin(t1, t2); outside = true; }
+    else { t = nanMax(t1, t2); outside = false; }
+    F3 objP = pointOnRay(ro, rd, t);
+    F3 P = mulMV(g.T, objP, 1.0f);
+    N = normalize(mulMV(g.IT, objP, 0.0f));
+    if (!outside) N = -N;
+    return length(r.o - P);
+}
+
+/* Moller-Trumbore on a hot triangle record (src/intersections.cu:268-308) */
+PT_DEV float hitTriangle(const float4* hot, F3 lo, F3 ld, F3& bary)
+{
+    const float EPS = 0.0000001f;
+    float4 a = hot[0], b = hot[1], c = hot[2];
+    F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+    F3 h = cross(ld, e2);
+    float det = dot(e1, h);
+    if (det > -EPS && det < EPS) return -1.0f;
+    float f = 1.0f / det;
+    F3 s = lo - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    F3 q = cross(s, e1);
+    float v = f * dot(ld, q);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    float t = f * dot(e2, q);
+    if (t > EPS) {
+        float w = 1.0f - u - v;
+        bary = f3(w, u, v);
+        return t;
+    }
+    return -1.0f;
+}
+
+/* Closest hit of one mesh.  Visits nodes in the order the reference's stack loop does
+ * (src/intersections.cu:344-386: left pushed, right pushed, right popped first) so that
+ * exact-distance ties resolve to the same triangle: descend into the right child, keep
+ * the left child (node+1) on the per-lane LDS stack.  stack points at this lane's column
+ * of a [kStackDepth][kBlock] LDS array.  Returns world distance or -1; attributes are
+ * fetched only when wantAttr (shadow queries need t alone). */
+template <bool COUNT>
+PT_DEV float hitMesh(const SceneView& S, const DGeom& g, const Ray& r, int* stack, bool wantAttr,
+                     F3& N, F2& uv, int& mat, int& triOrig, TravCounters& cnt)
+{
+    F3 lo = mulMV(g.I, r.o, 1.0f);
+    F3 ld = normalize(mulMV(g.I, r.d, 0.0f));
+    float closestT = 3.402823466e+38f;
+    int best = -1;
+    F3 bestBary = f3(0.0f);
+    const float4* hot = S.triHot + 3 * (size_t)g.triStart;
+
+    if (S.useBvh && g.hasBvh) {
+        F3 invDir = 1.0f / ld;
+        const float4* nodes = S.nodes + 2 * (size_t)g.nodeStart;
+        int sp = 0;
+        int node = 0;
+        while (true) {
+            float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
+            if (COUNT) cnt.nodes++;
+            F3 t0 = (f3(n0.x, n0.y, n0.z) - lo) * invDir;
+            F3 t1 = (f3(n1.x, n1.y, n1.z) - lo) * invDir;
+            F3 tlo = vmin(t0, t1);
+            F3 thi = vmax(t0, t1);
+            float tMin = selMax(selMax(tlo.x, tlo.y), tlo.z);
+            float tMax = selMin(selMin(thi.x, thi.y), thi.z);
+            bool enter = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);
+            int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
+            if (enter && b == 0) {              /* inner node */
+                if (sp < kStackDepth) { stack[sp * kBlock] = node + 1; sp++; }
+                node = a;
+                continue;
+            }
+            if (enter) {                        /* leaf */
+                for (int i = 0; i < b; ++i) {
+                    F3 bary;
+                    float tt = hitTriangle(hot + 3 * (size_t)(a + i), lo, ld, bary);
+                    if (COUNT) cnt.tris++;
+                    if (tt > 0.0f && tt < closestT) { closestT = tt; bestBary = bary; best = a + i; }
+                }
+            }
+            if (sp == 0) break;
+            sp--;
+            node = stack[sp * kBlock];
+        }
+    } else {
+        /* linear scan in ORIGINAL triangle order (meshIntersectionTest, src/intersections.cu:168-245) */
+        for (int i = 0; i < g.triCount; ++i) {
+            int leafPos = S.leafOfOrig[g.triStart + i];
+            F3 bary;
+            float tt = hitTriangle(hot + 3 * (size_t)leafPos, lo, ld, bary);
+            if (COUNT) cnt.tris++;
+            if (tt > 0.0f && tt < closestT) { closestT = tt; bestBary = bary; best = leafPos; }
+        }
+    }
+    if (best < 0) return -1.0f;
+    if (COUNT) cnt.meshHits++;
+    F3 localP = lo + ld * closestT;
+    F3 P = mulMV(g.T, localP, 1.0f);
+    if (wantAttr) {
+        const float4* cold = S.triCold + 4 * (size_t)(g.triStart + best);
+        float4 c0 = cold[0], c1 = cold[1], c2 = cold[2], c3 = cold[3];
+        F3 n0 = f3(c0.x, c0.y, c0.z), n1 = f3(c0.w, c1.x, c1.y), n2 = f3(c1.z, c1.w, c2.x);
+        F3 ln = normalize(bestBary.x * n0 + bestBary.y * n1 + bestBary.z * n2);
+        uv.x = (bestBary.x * c2.y + bestBary.y * c2.w) + bestBary.z * c3.y;
+        uv.y = (bestBary.x * c2.z + bestBary.y * c3.x) + bestBary.z * c3.z;
+        mat = __float_as_int(c3.w);
+        triOrig = __float_as_int(hot[3 * (size_t)best + 2].y);
+        N = normalize(mulMV(g.IT, ln, 0.0f));
+        bool outside = dot(r.d, N) < 0.0f;
+        if (!outside) N = -N;
+    }
+    return length(r.o - P);
+}
+
+/* closest hit over every geom, in geom order, strict '<' (src/pathtrace.cu:868-919) */
+template <bool COUNT>
+PT_DEV Hit closestHit(const SceneView& S, const Ray& r, int* stack, TravCounters& cnt)
+{
+    Hit h;
+    h.t = -1.0f; h.n = f3(0.0f); h.mat = 0; h.uv.x = 0.0f; h.uv.y = 0.0f; h.geom = -1; h.tri = -1;
+    float tMinAll = 3.402823466e+38f;
+    for (int i = 0; i < S.numGeoms; ++i) {
+        const DGeom& g = S.geoms[i];
+        float t = -1.0f;
+        F3 n = f3(0.0f);
+        F2 uv; uv.x = 0.5f; uv.y = 0.5f;
+        int mat = g.materialid, tri = -1;
+        if (g.type == PT_CUBE) t = hitBox(g, r, n);
+        else if (g.type == PT_SPHERE) t = hitSphere(g, r, n);
+        else if (g.type == PT_GLTF_MESH) t = hitMesh<COUNT>(S, g, r, stack, true, n, uv, mat, tri, cnt);
+        if (t > 0.0f && tMinAll > t) {
+            tMinAll = t;
+            h.t = t; h.n = n; h.mat = mat; h.uv = uv; h.geom = i; h.tri = tri;
+        }
+    }
+    return h;
+}
+
+/* distance of the closest hit on one geom, for shadow rays */
+template <bool COUNT>
+PT_DEV float occluderDistance(const SceneView& S, int gi, const Ray& r, int* stack, TravCounters& cnt)
+{
+    const DGeom& g = S.geoms[gi];
+    F3 n; F2 uv; int m, tri;
+    if (g.type == PT_SPHERE) return hitSphere(g, r, n);
+    if (g.type == PT_CUBE) return hitBox(g, r, n);
+    if (g.type == PT_GLTF_MESH) return hitMesh<COUNT>(S, g, r, stack, false, n, uv, m, tri, cnt);
+    return -1.0f;
+}
+
+/* ---------------------------------------------------------------- sampling */
+
+/* cosine-weighted hemisphere (src/interactions.cu:7-45) */
+PT_DEV F3 sampleHemisphere(F3 normal, Lcg& rng)
+{
+    float up = __builtin_sqrtf(rng.u01());
+    float over = __builtin_sqrtf(1 - up * up);
+    float around = rng.u01() * kTWO_PI;
+    F3 other;
+    if (__builtin_fabsf(normal.x) < kSQRT_OF_ONE_THIRD) other = f3(1, 0, 0);
+    else if (__builtin_fabsf(normal.y) < kSQRT_OF_ONE_THIRD) other = f3(0, 1, 0);
+    else other = f3(0, 0, 1);
+    F3 p1 = normalize(cross(normal, other));
+    F3 p2 = normalize(cross(normal, p1));
+    return up * normal + dm::cos(around) * over * p1 + dm::sin(around) * over * p2;
+}
+
+/* hand-written bilinear fetch on interleaved 8-bit texels, repeat wrap, no sRGB decode
+ * (src/pathtrace.cu:937-1019) */
+PT_DEV F4 fetchTexel(const DTexture& tex, int x, int y)
+{
+    int idx = (y * tex.width + x) * tex.components;
+    const uint8_t* d = tex.data;
+    F4 r;
+    if (tex.components == 3) { r.x = d[idx] / 255.0f; r.y = d[idx + 1] / 255.0f; r.z = d[idx + 2] / 255.0f; r.w = 1.0f; }
+    else if (tex.components == 4) {
+        uint32_t p = *reinterpret_cast<const uint32_t*>(d + idx);       /* one 4-byte load per RGBA texel */
+        r.x = (p & 255u) / 255.0f; r.y = ((p >> 8) & 255u) / 255.0f; r.z = ((p >> 16) & 255u) / 255.0f; r.w = (p >> 24) / 255.0f;
+    }
+    else if (tex.components == 1) { float v = d[idx] / 255.0f; r.x = v; r.y = v; r.z = v; r.w = 1.0f; }
+    else { r.x = 1.0f; r.y = 0.0f; r.z = 1.0f; r.w = 1.0f; }
+    return r;
+}
+PT_DEV F4 sampleTexture(const DTexture& tex, F2 uv)
+{
+    uv.x = uv.x - __builtin_floorf(uv.x);
+    uv.y = uv.y - __builtin_floorf(uv.y);
+    float fx = uv.x * (tex.width - 1);
+    float fy = uv.y * (tex.height - 1);
+    int x0 = (int)__builtin_floorf(fx);
+    int y0 = (int)__builtin_floorf(fy);
+    int x1 = min(x0 + 1, tex.width - 1);
+    int y1 = min(y0 + 1, tex.height - 1);
+    float wx = fx - x0;
+    float wy = fy - y0;
+    F4 p00 = fetchTexel(tex, x0, y0), p10 = fetchTexel(tex, x1, y0), p01 = fetchTexel(tex, x0, y1), p11 = fetchTexel(tex, x1, y1);
+    F4 p0 = p00 * (1.0f - wx) + p10 * wx;
+    F4 p1 = p01 * (1.0f - wx) + p11 * wx;
+    return p0 * (1.0f - wy) + p1 * wy;
+}
+
+PT_DEV F3 envTexel(const SceneView& S, int x, int y)
+{
+    const float* p = S.envData + 3 * ((size_t)y * S.envWidth + x);
+    return f3(p[0], p[1], p[2]);
+}
+/* equirect bilinear lookup with clamp, no seam wrap (src/pathtrace.cu:1030-1075) */
+PT_DEV F3 sampleEnv(const SceneView& S, F3 dir)
+{
+    if (!S.envEnabled) return f3(0.0f);
+    float theta = dm::acos(nanMax(-1.0f, nanMin(1.0f, dir.y)));
+    float phi = dm::atan2(dir.z, dir.x);
+    float u = (phi + kPI) / (2.0f * kPI);
+    float v = theta / kPI;
+    u = nanMax(0.0f, nanMin(1.0f, u));
+    v = nanMax(0.0f, nanMin(1.0f, v));
+    float fx = u * (S.envWidth - 1);
+    float fy = v * (S.envHeight - 1);
+    int x0 = (int)__builtin_floorf(fx);
+    int y0 = (int)__builtin_floorf(fy);
+    int x1 = min(x0 + 1, S.envWidth - 1);
+    int y1 = min(y0 + 1, S.envHeight - 1);
+    float wx = fx - x0;
+    float wy = fy - y0;
+    F3 p00 = envTexel(S, x0, y0), p10 = envTexel(S, x1, y0), p01 = envTexel(S, x0, y1), p11 = envTexel(S, x1, y1);
+    F3 p0 = p00 * (1.0f - wx) + p10 * wx;
+    F3 p1 = p01 * (1.0f - wx) + p11 * wx;
+    return p0 * (1.0f - wy) + p1 * wy;
+}
+
+/* point on an area light (src/pathtrace.cu:1091-1144) */
+PT_DEV F3 sampleLightPoint(const DGeom& g, Lcg& rng)
+{
+    if (g.type == PT_SPHERE) {
+        float u = rng.u01();
+        float v = rng.u01();
+        float theta = 2.0f * kPI * u;
+        float phi = dm::acos(1.0f - 2.0f * v);
+        float radius = g.scale[0] * 0.5f;
+        F3 local = f3(radius * dm::sin(phi) * dm::cos(theta), radius * dm::sin(phi) * dm::sin(theta), radius * dm::cos(phi));
+        return mulMV(g.T, local, 1.0f);
+    }
+    if (g.type == PT_CUBE) {
+        float faceChoice = rng.u01() * 6.0f;
+        int face = (int)faceChoice;
+        float u = rng.u01() - 0.5f;
+        float v = rng.u01() - 0.5f;
+        F3 local;
+        switch (face) {
+        case 0: local = f3(0.5f, u, v); break;
+        case 1: local = f3(-0.5f, u, v); break;
+        case 2: local = f3(u, 0.5f, v); break;
+        case 3: local = f3(u, -0.5f, v); break;
+        case 4: local = f3(u, v, 0.5f); break;
+        default: local = f3(u, v, -0.5f); break;
+        }
+        return mulMV(g.T, local, 1.0f);
+    }
+    return f3(g.translation);
+}
+
+/* first index with cdf[i] >= value (src/pathtrace.cu:1339-1354) */
+PT_DEV int lowerBound(const float* cdf, int size, float value)
+{
+    int left = 0, right = size - 1;
+    while (left < right) {
+        int mid = (left + right) / 2;
+        if (cdf[mid] < value) left = mid + 1; else right = mid;
+    }
+    return left;
+}
+
+/* env-map importance sample: row by marginal CDF, column by conditional CDF
+ * (src/pathtrace.cu:1412-1472) */
+PT_DEV F3 sampleEnvImportance(const SceneView& S, Lcg& rng, F3& outDir, float& outPdf)
+{
+    if (!S.envMarginal || !S.envConditional) {
+        outDir = sampleHemisphere(f3(0, 1, 0), rng);
+        outPdf = 1.0f / (2.0f * kPI);
+        return sampleEnv(S, outDir);
+    }
+    float u = rng.u01();
+    float v = rng.u01();
+    int y = lowerBound(S.envMarginal, S.envHeight, v);
+    y = min(y, S.envHeight - 1);
+    const float* rowCDF = S.envConditional + (size_t)y * S.envWidth;
+    int x = lowerBound(rowCDF, S.envWidth, u);
+    x = min(x, S.envWidth - 1);
+    float phi = (x + 0.5f) * 2.0f * kPI / S.envWidth - kPI;
+    float theta = (y + 0.5f) * kPI / S.envHeight;
+    float sinTheta = dm::sin(theta);
+    float cosTheta = dm::cos(theta);
+    outDir = normalize(f3(sinTheta * dm::cos(phi), cosTheta, sinTheta * dm::sin(phi)));
+    F3 color = envTexel(S, x, y);
+    float luminance = 0.299f * color.x + 0.587f * color.y + 0.114f * color.z;
+    float pdfImage = luminance * sinTheta;
+    if (S.envTotalPower > 0) pdfImage /= S.envTotalPower;
+    float pixelArea = (2.0f * kPI / S.envWidth) * (kPI / S.envHeight);
+    outPdf = pdfImage / (pixelArea * sinTheta);
+    outPdf = nanMax(outPdf, 1e-6f);
+    return color;
+}
+
+/* pdf of a direction under the env-map sampler (src/pathtrace.cu:1474-1511) */
+PT_DEV float envPdf(const SceneView& S, F3 dir)
+{
+    if (!S.envMarginal || !S.envConditional) return 1.0f / (2.0f * kPI);
+    float theta = dm::acos(nanMax(-1.0f, nanMin(1.0f, dir.y)));
+    float phi = dm::atan2(dir.z, dir.x);
+    float u = (phi + kPI) / (2.0f * kPI);
+    float v = theta / kPI;
+    int x = min((int)(u * S.envWidth), S.envWidth - 1);
+    int y = min((int)(v * S.envHeight), S.envHeight - 1);
+    F3 color = envTexel(S, x, y);
+    float luminance = 0.299f * color.x + 0.587f * color.y + 0.114f * color.z;
+    float sinTheta = dm::sin(theta);
+    float pdfImage = luminance * sinTheta;
+    if (S.envTotalPower > 0) pdfImage /= S.envTotalPower;
+    float pixelArea = (2.0f * kPI / S.envWidth) * (kPI / S.envHeight);
+    float pdf = pdfImage / (pixelArea * sinTheta);
+    return nanMax(pdf, 1e-6f);
+}
+
+/* shadow ray towards a sampled light point: blocked by the closest hit of any other geom
+ * lying strictly between the two ends (src/pathtrace.cu:2171-2226) */
+template <bool COUNT>
+PT_DEV bool lightVisible(const SceneView& S, const Ray& sh, int lightGeom, float dist, int* stack, TravCounters& cnt)
+{
+    for (int gi = 0; gi < S.numGeoms; ++gi) {
+        if (gi == lightGeom) continue;
+        float t = occluderDistance<COUNT>(S, gi, sh, stack, cnt);
+        if (t > 0.001f && t < dist - 0.001f) return false;
+    }
+    return true;
+}
+/* shadow ray towards the environment: any geom whose closest hit is at t >= 0.001 blocks
+ * (src/pathtrace.cu:2270-2294) */
+template <bool COUNT>
+PT_DEV bool envVisible(const SceneView& S, const Ray& sh, int* stack, TravCounters& cnt)
+{
+    bool visible = true;
+    for (int i = 0; i < S.numGeoms && visible; ++i) {
+        float t = occluderDistance<COUNT>(S, i, sh, stack, cnt);
+        visible = (t < 0.001f);
+    }
+    return visible;
+}
+
+/* ----------------------------------------------------------------- shaders */
+
+struct Path {
+    F3 o, d, color;
+    int remaining;
+    bool prevSpecular;
+};
+
+/* Lambert + one-sample direct light chosen among {light, BRDF, environment}
+ * (src/pathtrace.cu:2101-2327) */
+template <bool COUNT>
+PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 materialColor, Lcg& rng, int* stack, TravCounters& cnt)
+{
+    const int nl = S.numLights;
+    const bool env = S.envEnabled != 0;
+    F3 P = p.o + p.d * t;
+    const float MIN_PDF = 1e-6f, MAX_CONTRIBUTION = 20.0f;
+    F3 total = f3(0.0f);
+
+    float choice = rng.u01();
+    int strategy;
+    if (nl > 0 && env) strategy = choice < 0.33f ? 0 : (choice < 0.66f ? 1 : 2);
+    else if (nl > 0) strategy = choice < 0.5f ? 0 : 1;
+    else if (env) strategy = choice < 0.5f ? 1 : 2;
+    else strategy = 1;
+
+    if (strategy == 0 && nl > 0) {
+        int li = min((int)(rng.u01() * nl), nl - 1);
+        DLight L = S.lights[li];
+        const DGeom& lg = S.geoms[L.geomIdx];
+        const PtMaterial& lm = S.materials[lg.materialid];
+        F3 lp = sampleLightPoint(lg, rng);
+        F3 wi = lp - P;
+        float dist = length(wi);
+        if (dist > 0.01f) {
+            wi = wi / dist;
+            float NdotL = dot(normal, wi);
+            if (NdotL > 0.0f) {
+                Ray sh; sh.o = P + normal * 0.001f; sh.d = wi;
+                if (lightVisible<COUNT>(S, sh, L.geomIdx, dist, stack, cnt)) {
+                    F3 ln = normalize(lp - f3(lg.translation));
+                    float NdotLl = nanMax(0.0f, dot(-wi, ln));
+                    float pdfLight = 1.0f / (nanMax(L.area, 0.01f) * nl);
+                    float pdfBRDF = NdotL / kPI;
+                    float pdfE = env ? envPdf(S, wi) : 0.0f;
+                    float sum = pdfLight + pdfBRDF + pdfE;
+                    float weight = pdfLight / nanMax(sum, MIN_PDF);
+                    F3 Le = f3(lm.color) * lm.emittance;
+                    F3 f = materialColor / kPI;
+                    float G = NdotL * NdotLl / (dist * dist);
+                    float sp = (nl > 0 && env) ? 0.33f : ((nl > 0 || env) ? 0.5f : 1.0f);
+                    total = total + weight * Le * f * G * (float)nl / (sp * nanMax(pdfLight, MIN_PDF));
+                }
+            }
+        }
+    } else if (strategy == 2 && env) {
+        F3 ed; float ep;
+        F3 ec = sampleEnvImportance(S, rng, ed, ep);
+        float NdotL = dot(normal, ed);
+        if (NdotL > 0.0f) {
+            Ray sh; sh.o = P + normal * 0.001f; sh.d = ed;
+            if (envVisible<COUNT>(S, sh, stack, cnt)) {
+                float pdfBRDF = NdotL / kPI;
+                float sum = ep + pdfBRDF;
+                float weight = ep / nanMax(sum, MIN_PDF);
+                F3 f = materialColor / kPI;
+                float sp = (nl > 0 && env) ? 0.33f : 0.5f;
+                total = total + weight * ec * f * NdotL / (sp * nanMax(ep, MIN_PDF));
+            }
+        }
+    }
+    F3 dir = sampleHemisphere(normal, rng);
+    total = vclamp(total, f3(0.0f), f3(MAX_CONTRIBUTION));
+    p.color = p.color * (materialColor + total);
+    p.o = P + normal * 0.001f;
+    p.d = dir;
+}
+
+/* ideal mirror (src/pathtrace.cu:2329-2348) */
+PT_DEV void shadeMirror(Path& p, float t, F3 normal, F3 materialColor)
+{
+    F3 in = p.d;
+    F3 refl = normalize(in - 2.0f * dot(in, normal) * normal);
+    p.color = p.color * materialColor;
+    F3 P = p.o + p.d * t;
+    p.o = P + normal * 0.001f;
+    p.d = refl;
+}
+
+/* dielectric with Schlick reflectance, TIR handled first (src/pathtrace.cu:2350-2415) */
+PT_DEV void shadeDielectric(Path& p, float t, F3 normal, F3 materialColor, float ior, Lcg& rng)
+{
+    F3 in = normalize(p.d);
+    float cosTheta = dot(in, normal);
+    bool entering = cosTheta < 0.0f;
+    float etaI, etaT;
+    if (entering) { etaI = 1.0f; etaT = ior; cosTheta = -cosTheta; }
+    else { etaI = ior; etaT = 1.0f; normal = -normal; }
+    float eta = etaI / etaT;
+    float sin2T = eta * eta * (1.0f - cosTheta * cosTheta);
+    F3 nd;
+    if (sin2T > 1.0f) {
+        nd = normalize(in - 2.0f * dot(in, normal) * normal);
+    } else {
+        float cosT = __builtin_sqrtf(1.0f - sin2T);
+        float c = entering ? cosTheta : cosT;
+        float r0 = (1.0f - eta) / (1.0f + eta);
+        r0 = r0 * r0;
+        float fres = r0 + (1.0f - r0) * dm::pow5(1.0f - c);
+        if (rng.u01() < fres) nd = reflect(in, normal);
+        else nd = normalize(eta * in + (eta * cosTheta - cosT) * normal);
+    }
+    p.color = p.color * materialColor;
+    F3 P = p.o + p.d * t;
+    p.o = P + nd * 0.001f;
+    p.d = nd;
+}
+
+/* GGX terms (src/pathtrace.cu:1278-1337) */
+PT_DEV float ggxD(F3 n, F3 h, float rough)
+{
+    float a = rough * rough;
+    float a2 = a * a;
+    float nh = nanMax(0.0f, dot(n, h));
+    float nh2 = nh * nh;
+    float den = nh2 * (a2 - 1.0f) + 1.0f;
+    den = kPI * den * den;
+    return a2 / nanMax(0.0001f, den);
+}
+PT_DEV float ggxG1(F3 n, F3 v, float rough)
+{
+    float a = rough * rough;
+    float k = a / 2.0f;
+    float nv = nanMax(0.0f, dot(n, v));
+    float den = nv * (1.0f - k) + k;
+    return nv / nanMax(0.0001f, den);
+}
+PT_DEV F3 schlick(float c, F3 F0) { return F0 + (f3(1.0f) - F0) * dm::pow5(1.0f - c); }
+PT_DEV F3 sampleGgxHalf(F3 normal, float rough, Lcg& rng)
+{
+    float u = rng.u01();
+    float v = rng.u01();
+    float a = rough * rough;
+    float phi = 2.0f * kPI * u;
+    float ct = __builtin_sqrtf((1.0f - v) / (1.0f + (a * a - 1.0f) * v));
+    float st = __builtin_sqrtf(1.0f - ct * ct);
+    F3 ht = f3(st * dm::cos(phi), st * dm::sin(phi), ct);
+    F3 up = __builtin_fabsf(normal.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
+    F3 tx = normalize(cross(up, normal));
+    F3 ty = cross(normal, tx);
+    return tx * ht.x + ty * ht.y + normal * ht.z;
+}
+/* Cook-Torrance specular + Lambert diffuse for one light direction (src/pathtrace.cu:1898-1918) */
+PT_DEV F3 pbrBrdf(F3 n, F3 wo, F3 wi, float NdotL, float rough, float metallic, F3 albedo, F3 F0, float& D, float& NdotH, float& VdotH)
+{
+    F3 h = normalize(wi + wo);
+    float NdotV = nanMax(0.0f, dot(n, wo));
+    NdotH = nanMax(0.0f, dot(n, h));
+    VdotH = nanMax(0.0f, dot(wo, h));
+    D = ggxD(n, h, rough);
+    float G = ggxG1(n, wo, rough) * ggxG1(n, wi, rough);
+    F3 F = schlick(VdotH, F0);
+    F3 num = D * G * F;
+    float den = 4.0f * NdotV * NdotL;
+    F3 spec = num / nanMax(0.001f, den);
+    F3 kD = f3(1.0f) - F;
+    kD = kD * (1.0f - metallic);
+    F3 diff = kD * albedo / kPI;
+    return diff + spec;
+}
+
+/* dipole diffusion profile (src/pathtrace.cu:1518-1543) */
+PT_DEV F3 dipoleProfile(float r, F3 sa, F3 ssp)
+{
+    F3 stp = sa + ssp;
+    F3 str = vsqrt(3.0f * sa * stp);
+    F3 zr = f3(1.0f) / stp;
+    F3 zv = zr * (1.0f + 4.0f / 3.0f * f3(1.44f));
+    F3 dr = vsqrt(zr * zr + r * r);
+    F3 dv = vsqrt(zv * zv + r * r);
+    F3 C = f3(0.25f) / kPI;
+    F3 er = -str * dr, ev = -str * dv;
+    F3 xr = f3(dm::exp(er.x), dm::exp(er.y), dm::exp(er.z));
+    F3 xv = f3(dm::exp(ev.x), dm::exp(ev.y), dm::exp(ev.z));
+    F3 res = C * (zr * (str + f3(1.0f) / dr) * xr / (dr * dr) + zv * (str + f3(1.0f) / dv) * xv / (dv * dv));
+    return vclamp(res, f3(0.0f), f3(1.0f));
+}
+
+/* subsurface random-walk step of the PBR shader (src/pathtrace.cu:1546-1702); true when taken */
+PT_DEV bool shadeSubsurface(Path& p, F3 P, F3 normal, const PtMaterial& m, F3 materialColor, Lcg& rng)
+{
+    if (m.subsurfaceEnabled == 0 || m.metallic > 0.5f) return false;
+    float prob = 0.3f * (1.0f - m.metallic);
+    prob = selClamp(prob, 0.1f, 0.3f);
+    if (rng.u01() > prob) return false;
+
+    /* exit point */
+    float avg = (m.subsurfaceRadiusRGB[0] + m.subsurfaceRadiusRGB[1] + m.subsurfaceRadiusRGB[2]) / 3.0f;
+    avg *= m.subsurfaceScale;
+    avg = selClamp(avg, 0.001f, 1.0f);
+    float u = rng.u01();
+    float dist = -dm::log(1.0f - u * 0.9f) * avg;
+    dist = selClamp(dist, 0.001f, avg * 3.0f);
+    float theta = 2.0f * kPI * rng.u01();
+    float phi = dm::acos(1.0f - rng.u01());
+    F3 ld = f3(dm::sin(phi) * dm::cos(theta), dm::sin(phi) * dm::sin(theta), dm::cos(phi));
+    F3 tg = (__builtin_fabsf(normal.x) > __builtin_fabsf(normal.y)) ? normalize(f3(-normal.z, 0, normal.x)) : normalize(f3(0, -normal.z, normal.y));
+    F3 bt = cross(normal, tg);
+    F3 wd = tg * ld.x + bt * ld.y - normal * ld.z;
+    F3 exitP = P + normalize(wd) * dist;
+    float distance = length(exitP - P);
+
+    /* coefficients */
+    F3 A = f3(m.subsurfaceColor);
+    F3 safeR = vmax(f3(m.subsurfaceRadiusRGB) * m.subsurfaceScale, f3(0.001f));
+    F3 ssp = f3(1.0f) / safeR;
+    F3 sa = ssp * (f3(1.0f) - A) * 0.01f;
+    sa = vclamp(sa, f3(0.001f), f3(10.0f));
+    ssp = vclamp(ssp, f3(0.1f), f3(100.0f));
+
+    F3 bssrdf = dipoleProfile(distance, sa, ssp);
+    F3 e = -sa * distance;
+    F3 tr = f3(dm::exp(e.x), dm::exp(e.y), dm::exp(e.z));
+    tr = vclamp(tr, f3(0.0f), f3(1.0f));
+    F3 thr = bssrdf * tr * A;
+    thr = thr * mix(f3(1.0f), materialColor, 0.5f);
+    thr = thr * (1.0f / prob);
+    float mx = nanMax(nanMax(thr.x, thr.y), thr.z);
+    if (mx > 2.0f) thr = thr * (2.0f / mx);
+    p.color = p.color * thr;
+
+    float r1 = rng.u01();
+    float r2 = rng.u01();
+    float st = __builtin_sqrtf(r1);
+    float ct = __builtin_sqrtf(1.0f - r1);
+    float ph = 2.0f * kPI * r2;
+    F3 l2 = f3(st * dm::cos(ph), st * dm::sin(ph), ct);
+    F3 w2 = tg * l2.x + bt * l2.y + normal * l2.z;     /* same tangent frame: exit normal == entry normal */
+    p.o = exitP + normal * 0.001f;
+    p.d = normalize(w2);
+    p.remaining--;
+    return true;
+}
+
+/* metallic-roughness shader: optional subsurface step, stochastic transmission, one-sample
+ * direct light with the reference's weights, GGX / cosine lobe pick (src/pathtrace.cu:1708-2099) */
+template <bool COUNT>
+PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMaterial& m, float roughIn, float metallic,
+                     F3 albedo, float texAlpha, Lcg& rng, int* stack, TravCounters& cnt)
+{
+    const int nl = S.numLights;
+    const bool env = S.envEnabled != 0;
+    F3 P = p.o + p.d * t;
+
+    if (m.subsurfaceEnabled > 0 && metallic < 0.5f) {
+        PtMaterial mm = m;
+        mm.metallic = metallic;
+        if (shadeSubsurface(p, P, normal, mm, albedo, rng)) return;
+    }
+    F3 wo = -p.d;
+    float rough = selClamp(roughIn, 0.02f, 1.0f);
+
+    float transp = m.transparency;
+    if (texAlpha < 1.0f) {
+        float tt = 1.0f - texAlpha;
+        transp = 1.0f - ((1.0f - transp) * (1.0f - tt));
+    }
+    if (transp > 0.0f && rng.u01() < transp) {
+        float ior = m.indexOfRefraction > 0 ? m.indexOfRefraction : 1.5f;
+        bool entering = dot(normal, wo) > 0;
+        F3 n = entering ? normal : -normal;
+        float eta = entering ? (1.0f / ior) : ior;
+        float c = dot(n, wo);
+        float k = 1.0f - eta * eta * (1.0f - c * c);
+        F3 nd;
+        if (k < 0.0f || rough > 0.8f) nd = p.d;
+        else nd = normalize(eta * (-wo) + (eta * c - __builtin_sqrtf(k)) * n);
+        p.o = P - n * 0.001f;
+        if (rough > 0.1f && rough < 0.8f) {
+            float sx = rng.u01() - 0.5f;            /* drawn in x, y, z order */
+            float sy = rng.u01() - 0.5f;
+            float sz = rng.u01() - 0.5f;
+            F3 sc = f3(sx, sy, sz) * rough * 0.2f;
+            nd = normalize(nd + sc);
+        }
+        p.d = nd;
+        p.color = p.color * mix(f3(1.0f), albedo, 1.0f - transp);
+        return;
+    }
+
+    F3 F0 = mix(f3(0.04f), albedo, metallic);
+    const float MIN_PDF = 1e-6f, MAX_CONTRIBUTION = 10.0f;
+    F3 direct = f3(0.0f);
+
+    float choice = rng.u01();
+    int strategy = 1;
+    if (nl > 0 && env) strategy = choice < 0.33f ? 0 : (choice < 0.66f ? 1 : 2);
+    else if (nl > 0 && !env) strategy = choice < 0.5f ? 0 : 1;
+    else if (nl == 0 && env) strategy = choice < 0.5f ? 1 : 2;
+
+    if (strategy == 0 && nl > 0) {
+        int li = min((int)(rng.u01() * nl), nl - 1);
+        DLight L = S.lights[li];
+        const DGeom& lg = S.geoms[L.geomIdx];
+        const PtMaterial& lm = S.materials[lg.materialid];
+        F3 lp = sampleLightPoint(lg, rng);
+        F3 wi = lp - P;
+        float dist = length(wi);
+        if (dist > 0.01f) {
+            wi = wi / dist;
+            float NdotL = dot(normal, wi);
+            if (NdotL > 0.0f) {
+                Ray sh; sh.o = P + normal * 0.001f; sh.d = wi;
+                if (lightVisible<COUNT>(S, sh, L.geomIdx, dist, stack, cnt)) {
+                    float D, NdotH, VdotH;
+                    F3 brdf = pbrBrdf(normal, wo, wi, NdotL, rough, metallic, albedo, F0, D, NdotH, VdotH);
+                    F3 ln = normalize(lp - f3(lg.translation));
+                    float NdotLl = nanMax(0.0f, dot(-wi, ln));
+                    float pdfLight = 1.0f / (nanMax(L.area, 0.01f) * nl);
+                    float pdfBRDF = (NdotL / kPI) * (1.0f - metallic) + (D * NdotH / (4.0f * VdotH)) * metallic;
+                    float pdfE = env ? envPdf(S, wi) : 0.0f;
+                    float sum = pdfLight + pdfBRDF + pdfE;
+                    float weight = pdfLight / nanMax(sum, MIN_PDF);
+                    F3 Le = f3(lm.color) * lm.emittance;
+                    float G = NdotL * NdotLl / (dist * dist);
+                    float sp = (nl > 0 && env) ? 0.33f : ((nl > 0 || env) ? 0.5f : 1.0f);
+                    direct = direct + weight * brdf * Le * G * (float)nl / (sp * nanMax(pdfLight, MIN_PDF));
+                }
+            }
+        }
+    } else if (strategy == 2 && env) {
+        F3 ed; float ep;
+        F3 ec = sampleEnvImportance(S, rng, ed, ep);
+        float NdotL = dot(normal, ed);
+        if (NdotL > 0.0f) {
+            Ray sh; sh.o = P + normal * 0.001f; sh.d = ed;
+            if (envVisible<COUNT>(S, sh, stack, cnt)) {
+                float D, NdotH, VdotH;
+                F3 brdf = pbrBrdf(normal, wo, ed, NdotL, rough, metallic, albedo, F0, D, NdotH, VdotH);
+                float pdfBRDF = (NdotL / kPI) * (1.0f - metallic) + (D * NdotH / (4.0f * VdotH)) * metallic;
+                float sum = ep + pdfBRDF;
+                float weight = ep / nanMax(sum, MIN_PDF);
+                float sp = (nl > 0 && env) ? 0.33f : (env ? 0.5f : 1.0f);
+                direct = direct + weight * brdf * ec * NdotL / (sp * nanMax(ep, MIN_PDF));
+            }
+        }
+    }
+    direct = vclamp(direct, f3(0.0f), f3(MAX_CONTRIBUTION));
+
+    float specProb = 0.5f + 0.5f * metallic;
+    if (rng.u01() < specProb) {
+        F3 h = sampleGgxHalf(normal, rough, rng);
+        F3 wi = reflect(-wo, h);
+        if (dot(wi, normal) > 0.0f) {
+            float VdotH = nanMax(0.0f, dot(wo, h));
+            F3 F = schlick(VdotH, F0);
+            F3 sc = mix(f3(1.0f), albedo, metallic);
+            p.color = p.color * ((sc * F / specProb) + direct);
+            p.o = P + normal * 0.001f;
+            p.d = wi;
+            p.prevSpecular = true;
+        } else {
+            p.remaining = 0;
+            p.color = f3(0.0f);
+        }
+    } else {
+        if (metallic < 1.0f) {
+            F3 wi = sampleHemisphere(normal, rng);
+            F3 dc = albedo * (1.0f - metallic);
+            p.color = p.color * ((dc / (1.0f - specProb)) + direct);
+            p.o = P + normal * 0.001f;
+            p.d = wi;
+            p.prevSpecular = false;
+        } else {
+            p.remaining = 0;
+            p.color = f3(0.0f);
+        }
+    }
+    p.remaining--;
+}
+
+/* one queue slot of the shade stage: Russian roulette, textures, emission, material
+ * dispatch, miss / environment (shadeMaterialMIS, src/pathtrace.cu:2455-2626) */
+template <bool COUNT>
+PT_DEV void shadeSlot(const SceneView& S, int iter, int bounceOneBased, int slot, Path& p, float t, F3 normal, int matId, F2 uv,
+                      bool firstBounce, int* stack, TravCounters& cnt)
+{
+    if (p.remaining <= 0) return;
+    Lcg rng;
+    rng.seed(iter, slot, p.remaining);
+
+    if (bounceOneBased >= 3) {          /* RR_START_BOUNCE (src/sceneStructs.h:12) */
+        float lum = 0.2126f * p.color.x + 0.7152f * p.color.y + 0.0722f * p.color.z;
+        float survive = selClamp(lum, 0.05f, 0.95f);
+        if (rng.u01() >= survive) { p.remaining = 0; p.color = f3(0.0f); return; }
+        p.color = p.color / survive;
+    }
+
+    if (t > 0.0f) {
+        const PtMaterial& m = S.materials[matId];
+        F3 mc = f3(m.color);
+        float alpha = 1.0f;
+        float metallic = m.metallic, rough = m.roughness;
+        if (m.baseColorTextureIdx >= 0 && m.baseColorTextureIdx < S.numTextures) {
+            F4 c = sampleTexture(S.textures[m.baseColorTextureIdx], uv);
+            mc = f3(c.x, c.y, c.z);
+            alpha = c.w;
+            mc = mc * f3(m.color);
+        }
+        if (m.metallicRoughnessTextureIdx >= 0 && m.metallicRoughnessTextureIdx < S.numTextures) {
+            F4 mr = sampleTexture(S.textures[m.metallicRoughnessTextureIdx], uv);
+            metallic *= mr.z;
+            rough *= mr.y;
+        }
+        if (m.emissiveTextureIdx >= 0 && m.emissiveTextureIdx < S.numTextures) {
+            F4 e4 = sampleTexture(S.textures[m.emissiveTextureIdx], uv);
+            F3 em = f3(e4.x, e4.y, e4.z);
+            if (length(em) > 0.0f) {
+                p.color = p.color * (em * f3(m.emissiveFactor));
+                p.remaining = 0;
+                return;
+            }
+        }
+        if (m.emittance > 0.0f) {
+            p.color = p.color * (mc * m.emittance);
+            p.remaining = 0;
+            return;
+        }
+        p.remaining--;
+        if (p.remaining <= 0) { p.color = f3(0.0f); return; }
+
+        switch (m.type) {
+        case PT_DIFFUSE:
+            p.prevSpecular = false;
+            shadeDiffuse<COUNT>(S, p, t, normal, mc, rng, stack, cnt);
+            break;
+        case PT_SPECULAR:
+            p.prevSpecular = true;
+            shadeMirror(p, t, normal, mc);
+            break;
+        case PT_REFRACTIVE:
+            p.prevSpecular = true;
+            shadeDielectric(p, t, normal, mc, m.indexOfRefraction, rng);
+            break;
+        case PT_PBR:
+            p.prevSpecular = (rough < 0.1f && metallic > 0.5f);
+            shadePbr<COUNT>(S, p, t, normal, m, rough, metallic, mc, alpha, rng, stack, cnt);
+            break;
+        default:
+            p.prevSpecular = false;
+            break;
+        }
+    } else {
+        if (S.envEnabled) {
+            F3 ec = sampleEnv(S, p.d);
+            if (firstBounce) p.color = p.color * ec;
+            else if (p.prevSpecular) p.color = p.color * ec;
+            else p.color = p.color * (ec * 0.5f);
+        } else {
+            p.color = p.color * f3(0.0f);
+        }
+        p.remaining = 0;
+    }
+}
+
+} // namespace ptd

@@ -317,8 +317,15 @@ def make_scene(name, res=None, depth=None, directory=None, tex_size=1024, env_si
         trs = (mesh_obj["TRANS"], mesh_obj["ROTAT"], mesh_obj["SCALE"])
         ids = _mesh_materials(sc, name, cfg, tex_size)
         g = grid or cfg["grid"]
-        tris = blob_mesh(g[0], g[1], seed=1, trs=trs, material_ids=ids, center=(0.0, 1.6, 0.0), squash=(1.35, 1.0, 0.8),
-                         radius=1.5)
+        # The object's TRS reaches the rays twice (baked into the triangles and again as the geom transform,
+        # src/scene.cpp:265 + src/intersections.cu:325-326), so place the local blob where M*M maps it onto
+        # the part of the room the camera looks at.
+        M = build_transforms(*trs)[0].T.astype(np.float64)
+        M2 = M @ M
+        s2 = abs(np.linalg.det(M2[:3, :3])) ** (1.0 / 3.0)
+        centre = np.linalg.solve(M2, np.array([0.0, 4.2, 0.0, 1.0]))[:3]
+        tris = blob_mesh(g[0], g[1], seed=1, trs=trs, material_ids=ids, center=tuple(centre), squash=(1.25, 1.0, 0.8),
+                         radius=3.0 / s2)
         sc.add_mesh(tris, *trs)
         want_env = cfg["env"] if env is None else env
         if want_env:

@@ -1583,9 +1583,10 @@ void oracle_rng_u01(int iter, int index, int depth, int n, float* out)
     Rng r(iter, index, depth);
     for (int i = 0; i < n; i++) out[i] = r.u01();
 }
-void oracle_hemisphere(Oracle* o, int iter, int index, int depth, const float normal[3], float out[3])
+void oracle_hemisphere(Oracle* o, int iter, int index, int depth, int skip, const float normal[3], float out[3])
 {
     Rng r(iter, index, depth);
+    for (int i = 0; i < skip; i++) r.u01();
     V3 d = hemisphereCosine(o ? *o->M : kLibm, V3(normal), r);
     out[0] = d.x; out[1] = d.y; out[2] = d.z;
 }
@@ -1604,6 +1605,11 @@ float oracle_math_eval(int mode, int fn, float a, float b)
     case 8: return sqrtf(a);
     default: return 0.0f;
     }
+}
+
+void oracle_math_eval_array(int mode, int fn, const float* a, const float* b, int n, float* out)
+{
+    for (int i = 0; i < n; i++) out[i] = oracle_math_eval(mode, fn, a[i], b ? b[i] : 0.0f);
 }
 
 int oracle_bvh_build(const PtTriangle* tris, int n, int maxDepth, PtBvhNode** nodes, int* nodeCount,

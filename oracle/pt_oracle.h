@@ -43,8 +43,9 @@ void oracle_intersect_rays_linear(Oracle* o, const float* origins, const float* 
 
 /* known-answer helpers */
 void oracle_rng_u01(int iter, int index, int depth, int n, float* out);
-void oracle_hemisphere(Oracle* o, int iter, int index, int depth, const float normal[3], float out[3]);
+void oracle_hemisphere(Oracle* o, int iter, int index, int depth, int skip, const float normal[3], float out[3]);
 float oracle_math_eval(int mode, int fn, float a, float b);
+void oracle_math_eval_array(int mode, int fn, const float* a, const float* b, int n, float* out);
 
 /* the oracle's own BVH build (BVH::build restated); returns node/leaf/depth counts */
 int oracle_bvh_build(const PtTriangle* tris, int n, int maxDepth,

@@ -1,0 +1,284 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars:
+  * arithmetic primitives (div, sqrt, sin/cos/acos/atan2/exp/log)  bit-exact vs the oracle's det mode
+  * camera rays                                                     bit-exact
+  * closest hit on fixed ray sets (geom, triangle, t, normal, uv)   bit-exact
+  * whole iterations (image sum, live-path curve, path-bounce total) bit-exact vs the oracle's det mode
+  * accumulated radiance vs the oracle's libm mode (the arithmetic a host build of the
+    reference performs): per-channel RMSE <= RMSE_TOL of the mean radiance after SPP samples
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RMSE_TOL = 0.02     # per-channel RMSE of (gpu - oracle_libm) / mean radiance over the image, 16 spp at 96x96
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _same_bits(a, b):
+    a, b = _bits(a), _bits(b)
+    nan = (np.isnan(a.view(np.float32)) & np.isnan(b.view(np.float32)))
+    return bool(np.all((a == b) | nan))
+
+
+def _ray_set(seed, n, center=(0.0, 5.0, 0.0), radius=9.0):
+    """Seeded rays: origins on a sphere around the scene, directions towards a jittered interior point."""
+    rng = np.random.RandomState(seed)
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    o = np.asarray(center) + radius * v
+    tgt = np.asarray(center) + rng.uniform(-4, 4, size=(n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+def _hits_equal(g, o):
+    for f in ("geom", "triangle", "materialId"):
+        assert np.array_equal(g[f], o[f]), f
+    assert _same_bits(g["t"], o["t"])
+    hit = o["t"] > 0
+    assert _same_bits(g["normal"][hit], o["normal"][hit])
+    assert _same_bits(g["uv"][hit], o["uv"][hit])
+
+
+@pytest.mark.parametrize("fn,lo,hi", [("sin", -7.0, 7.0), ("cos", -7.0, 7.0), ("acos", -1.0, 1.0), ("exp", -90.0, 10.0),
+                                      ("log", 1e-3, 10.0), ("pow5", 0.0, 1.0), ("sqrt", 0.0, 100.0)])
+def test_math_unary_bit_exact(pt, orc, gpu_ok, fn, lo, hi):
+    rng = np.random.RandomState(5)
+    x = rng.uniform(lo, hi, 1 << 16).astype(np.float32)
+    x[:8] = [lo, hi, 0.0, 1.0, -1.0 if lo < 0 else 0.5, 0.5, 0.25, (lo + hi) / 2]
+    x = np.clip(x, lo, hi).astype(np.float32)
+    g = pt.math_eval(orc.FN[fn], x)
+    o = orc.math_eval(orc.MATH_DET, fn, x)
+    assert _same_bits(g, o)
+
+
+@pytest.mark.parametrize("fn", ["atan2", "div"])
+def test_math_binary_bit_exact(pt, orc, gpu_ok, fn):
+    rng = np.random.RandomState(6)
+    a = rng.uniform(-3, 3, 1 << 16).astype(np.float32)
+    b = rng.uniform(-3, 3, 1 << 16).astype(np.float32)
+    a[:4] = [0.0, 0.0, 1.0, -1.0]
+    b[:4] = [1.0, -1.0, 0.0, 0.0]
+    b[b == 0] = np.float32(0.5) if fn == "div" else b[b == 0]
+    g = pt.math_eval(orc.FN[fn], a, b)
+    o = orc.math_eval(orc.MATH_DET, fn, a, b)
+    assert _same_bits(g, o)
+
+
+def test_camera_rays_bit_exact(pt, scenes, orc, gpu_ok):
+    sc = scenes.make_scene("cornell", res=(200, 120), depth=8)
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    for it in (1, 2, 3, 4, 7):
+        go, gd = tr.camera_rays(it)
+        oo, od = o.camera_rays(it)
+        assert _same_bits(go, oo) and _same_bits(gd, od)
+
+
+@pytest.mark.parametrize("name", ["cornell", "sss", "pbr", "ssaa"])
+def test_closest_hit_primitives_bit_exact(pt, scenes, orc, gpu_ok, name):
+    sc = scenes.make_scene(name, res=(64, 64))
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    ro, rd = _ray_set(11, 20000)
+    # axis-parallel rays exercise the unguarded division by zero in the slab test
+    ro[:6] = [[0, 5, 9], [0, 5, 9], [3, 5, 0], [0, 9.9, 0], [0, 5, 0], [0, 5, 0]]
+    rd[:6] = [[0, 0, -1], [0, 1, 0], [-1, 0, 0], [0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    _hits_equal(tr.intersect(ro, rd), o.intersect(ro, rd))
+
+
+def test_closest_hit_mesh_bit_exact(pt, scenes, orc, gpu_ok):
+    sc = scenes.make_scene("dragon", res=(64, 64), grid=(64, 65), env_size=(64, 32), tex_size=16)
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    ro, rd = _ray_set(3, 50000, center=(0.0, 4.0, 0.0), radius=12.0)
+    g = tr.intersect(ro, rd)
+    ob = o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    assert (g["triangle"] >= 0).sum() > 5000
+    # the BVH path agrees with brute force over every triangle (topology-independent check)
+    lin = o.intersect(ro[:4000], rd[:4000], linear=True)
+    assert np.array_equal(lin["triangle"], ob["triangle"][:4000]) and _same_bits(lin["t"], ob["t"][:4000])
+    # USE_BVH = 0: linear fallback on the device
+    tr.set_option(pt.PT_OPT_USE_BVH, 0)
+    _hits_equal(tr.intersect(ro[:4000], rd[:4000]), lin)
+
+
+def test_closest_hit_cube_mesh_ties(pt, scenes, orc, gpu_ok):
+    """12-triangle axis-aligned cube: rays through shared edges / vertices give exact-distance ties."""
+    sc = scenes.make_scene("cornell_orig", res=(32, 32))
+    trs = ((0.0, 5.0, 0.0), (0.0, 0.0, 0.0), (2.0, 2.0, 2.0))
+    mid = sc.add_material(type=pt.PT_PBR, color=[0.8, 0.8, 0.8], roughness=0.5, metallic=0.0, indexOfRefraction=1.5)
+    sc.add_mesh(scenes.cube_mesh(trs, mid))      # vertices pre-placed, identity object transform
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    xs = np.linspace(-1.0, 1.0, 41, dtype=np.float32)
+    gx, gy = np.meshgrid(xs, xs)
+    n = gx.size
+    ro = np.stack([gx.ravel(), 5 + gy.ravel(), np.full(n, 9.0, np.float32)], 1).astype(np.float32)
+    rd = np.tile(np.array([[0, 0, -1]], np.float32), (n, 1))
+    # diagonal rays through the cube's corners and edge midpoints
+    ro2 = np.array([[0, 5, 9], [4, 9, 4], [-4, 5, 4], [0, 9, 0]], np.float32)
+    rd2 = np.array([[0, 0, -1], [-1, -1, -1], [1, 0, -1], [0, -1, 0]], np.float32)
+    rd2 /= np.linalg.norm(rd2, axis=1, keepdims=True)
+    ro, rd = np.concatenate([ro, ro2]), np.concatenate([rd, rd2])
+    g, ob = tr.intersect(ro, rd), o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    assert (ob["triangle"] >= 0).sum() > 100
+
+
+def _render_pair(pt, orc, sc, iters, math, sort=1):
+    tr = pt.Tracer(sc)
+    tr.set_option(pt.PT_OPT_MATERIAL_SORT, sort)
+    o = orc.Oracle(pt, sc, math)
+    o.set_option(pt.PT_OPT_MATERIAL_SORT, sort)
+    curves = []
+    for it in iters:
+        tr.trace(it)
+        o.trace(it)
+        gs, os_ = tr.stats(), o.stats()
+        curves.append((list(gs.lastLive[:sc.depth + 1]), list(os_.lastLive[:sc.depth + 1]), gs.lastDepth, os_.lastDepth))
+    return tr, o, curves
+
+
+def _assert_full_parity(pt, orc, sc, iters, sort=1, lit=True):
+    tr, o, curves = _render_pair(pt, orc, sc, iters, orc.MATH_DET, sort)
+    for g, ob, gd, od in curves:
+        assert g == ob, (g, ob)
+        assert gd == od
+    gs, os_ = tr.stats(), o.stats()
+    assert gs.pathBounces == os_.pathBounces
+    gi, oi = tr.image(), o.image()
+    assert _same_bits(gi, oi), "max abs diff %g" % np.nanmax(np.abs(gi - oi))
+    if lit is not None:
+        assert (float(oi.sum()) > 0) == lit
+    return tr, o
+
+
+@pytest.mark.parametrize("name,res,depth", [("cornell", (128, 128), 8), ("cornell", (97, 61), 12), ("sss", (96, 96), 8),
+                                           ("pbr", (96, 96), 8), ("ssaa", (96, 96), 8), ("cornell_orig", (64, 64), 8),
+                                           ("spheres", (64, 64), 8)])
+def test_iterations_bit_exact_primitives(pt, scenes, orc, gpu_ok, name, res, depth):
+    sc = scenes.make_scene(name, res=res, depth=depth)
+    _assert_full_parity(pt, orc, sc, [1, 2, 3, 4, 5], lit=name != "spheres")    # no light and no env map: black
+
+
+def test_iterations_bit_exact_env_map(pt, scenes, orc, gpu_ok):
+    """All three MIS strategies (light / BRDF / environment CDF sampling) and miss shading."""
+    for name in ("pbr", "cornell", "spheres"):
+        sc = scenes.make_scene(name, res=(96, 96), depth=8, env=True, env_size=(256, 128))
+        _assert_full_parity(pt, orc, sc, [1, 2, 3])
+
+
+def test_iterations_bit_exact_mesh_textures_env(pt, scenes, orc, gpu_ok):
+    """Mesh + BVH shadow rays + RGBA / metallic-roughness textures + transmissive material + env map."""
+    sc = scenes.make_scene("chess", res=(96, 96), depth=10, grid=(48, 49), env_size=(128, 64), tex_size=32)
+    _assert_full_parity(pt, orc, sc, [1, 2, 3])
+    sc = scenes.make_scene("dragon", res=(128, 72), depth=8, grid=(64, 65), env_size=(128, 64), tex_size=32)
+    _assert_full_parity(pt, orc, sc, [1, 2])
+    sc = scenes.make_scene("halo", res=(64, 64), depth=8, grid=(40, 41), env_size=(64, 32), tex_size=16)
+    _assert_full_parity(pt, orc, sc, [1, 2])
+    sc = scenes.make_scene("duck", res=(64, 64), depth=8, env_size=(64, 32), tex_size=16)   # no light geom at all
+    _assert_full_parity(pt, orc, sc, [1, 2])
+
+
+def test_material_sort_off_bit_exact(pt, scenes, orc, gpu_ok):
+    """MATERIAL_SORTING 0 (src/pathtrace.h:6): slots keep compacted order, so RNG streams differ from sort-on."""
+    sc = scenes.make_scene("cornell", res=(96, 96), depth=8)
+    tr, o = _assert_full_parity(pt, orc, sc, [1, 2, 3], sort=0)
+    tr2, _ = _assert_full_parity(pt, orc, sc, [1, 2, 3], sort=1)
+    assert not np.array_equal(tr.image(), tr2.image())
+
+
+def test_depth_one_and_tiny_images(pt, scenes, orc, gpu_ok):
+    for res, depth in (((1, 1), 8), ((3, 2), 1), ((257, 1), 2), ((16, 16), 1)):
+        sc = scenes.make_scene("cornell", res=res, depth=depth)
+        _assert_full_parity(pt, orc, sc, [1, 2], lit=None)
+
+
+def test_radiance_rmse_vs_reference_arithmetic(pt, scenes, orc, gpu_ok):
+    """GPU (fixed-sequence math) vs the oracle in libm mode (glibc sinf/cosf/...): paths whose branch
+    decisions flip diverge, so the comparison is statistical."""
+    sc = scenes.make_scene("cornell", res=(96, 96), depth=8)
+    spp = 16
+    tr, o, _ = _render_pair(pt, orc, sc, range(1, spp + 1), orc.MATH_LIBM)
+    gi, oi = tr.image() / spp, o.image() / spp
+    mean = oi.reshape(-1, 3).mean(0)
+    rmse = np.sqrt(((gi - oi) ** 2).reshape(-1, 3).mean(0))
+    assert np.all(rmse / mean <= RMSE_TOL), (rmse / mean)
+    assert np.allclose(gi.reshape(-1, 3).mean(0), mean, rtol=5e-3)
+
+
+def test_display_clear_upload_bind(pt, scenes, orc, gpu_ok):
+    import torch
+    sc = scenes.make_scene("cornell", res=(64, 48), depth=8)
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    for it in (1, 2):
+        tr.trace(it)
+        o.trace(it)
+    rgba = torch.zeros(48 * 64 * 4, dtype=torch.uint8, device="cuda")
+    tr.display(2, rgba.data_ptr())
+    tr.sync()
+    assert np.array_equal(rgba.cpu().numpy().reshape(48, 64, 4), o.display(2))
+    # the running sum can live in caller memory (a torch tensor) ...
+    img2 = torch.zeros(48 * 64 * 3, dtype=torch.float32, device="cuda")
+    snapshot = tr.image()
+    tr.bind_image(img2.data_ptr())
+    tr.trace(1)
+    tr.trace(2)
+    tr.sync()
+    assert _same_bits(img2.cpu().numpy().reshape(48, 64, 3), snapshot)
+    tr.bind_image(0)
+    # ... be cleared, and be reloaded (resume = reload the sum)
+    tr.clear()
+    assert float(tr.image().sum()) == 0.0
+    tr.upload_image(snapshot)
+    tr.trace(3)
+    o.trace(3)
+    assert _same_bits(tr.image(), o.image())
+
+
+def test_sample_split_equals_single_render(pt, scenes, orc, gpu_ok):
+    """Iterations interleaved over R contexts and summed == one context rendering them all (up to fp32 order)."""
+    sc = scenes.make_scene("cornell", res=(64, 64), depth=8)
+    single = pt.Tracer(sc)
+    single.trace_range(1, 9)
+    parts = []
+    for r in range(2):
+        t = pt.Tracer(sc)
+        t.trace_range(1 + r, 9, 2)
+        parts.append(t.image())
+    a, b = single.image(), parts[0] + parts[1]
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert single.stats().pathBounces > 0
+
+
+def test_counters_match_oracle(pt, scenes, orc, gpu_ok):
+    sc = scenes.make_scene("dragon", res=(64, 64), depth=4, grid=(48, 49), env_size=(64, 32), tex_size=16)
+    tr = pt.Tracer(sc)
+    tr.set_option(pt.PT_OPT_COUNTERS, 1)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    tr.trace(1)
+    o.trace(1)
+    gs, os_ = tr.stats(), o.stats()
+    assert (gs.nodesVisited, gs.trisTested, gs.meshHits) == (os_.nodesVisited, os_.trisTested, os_.meshHits)
+    assert gs.nodesVisited > 0
+
+
+def test_errors_are_reported(pt, scenes, gpu_ok):
+    sc = scenes.make_scene("cornell", res=(16, 16), depth=8)
+    with pytest.raises(pt.PtError):
+        pt.Tracer(sc, device=99)
+    d = sc.desc.contents
+    d.traceDepth = 0
+    with pytest.raises(pt.PtError):
+        pt.Tracer(sc)
+    assert pt.lib.pt_destroy(None) == 0          # pathtraceFree before the first init is a no-op
