@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the wavefront path-tracing loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one iteration of the wavefront loop (one sample per pixel) on every rank.  Ranks render
+disjoint, interleaved iteration indices of the same replicated scene (iterations are independent given
+the iteration index, which seeds every RNG stream); after the timed steps the per-rank running sums are
+summed with one all-reduce over RCCL.  value = path-bounces of all ranks / time (path-bounce = one live
+path entering the intersect stage for one bounce).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, resolution, depth, description)
+    "dragon": ("dragon", (1920, 1080), 8,
+               "dragon.json @1920x1080 depth 8 (procedural stand-in for the undistributed DragonAttenuation.glb: "
+               "135200-triangle closed mesh, 6 PBR materials incl. one transmissive, cube light, "
+               "2048x1024 procedural HDR env, intensity 0.6)"),
+    "cornell": ("cornell", (800, 800), 8, "cornell.json @800x800 depth 8, env map absent (9 primitives, 13 materials)"),
+    "chess": ("chess", (1920, 1080), 10, "chess.json @1920x1080 depth 10 (stand-in: 1.5M triangles, 18 textured PBR materials, HDR env)"),
+    "sss": ("sss", (1920, 1080), 8, "sss.json @1920x1080 depth 8"),
+    "halo": ("halo", (3840, 2160), 8, "halo.json @3840x2160 depth 8 (stand-in: 3.0M triangles, 13 materials, two lights, HDR env)"),
+}
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sort", action="store_true", help="MATERIAL_SORTING 0")
+    ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=0, help="iterations sharing one launch group (0 = library default)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    pt = entry._load_package()
+    scenes = importlib.import_module("cuda_path_tracer_amd.scenes")
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene_name, res, depth, desc = WORKLOADS[args.workload]
+    sc = scenes.make_scene(scene_name, res=res, depth=depth)
+    tr = pt.Tracer(sc, device=local_rank)
+    if args.no_sort:
+        tr.set_option(pt.PT_OPT_MATERIAL_SORT, 0)
+    npix = res[0] * res[1]
+    image = torch.zeros(npix * 3, dtype=torch.float32, device="cuda")      # running sum lives in a torch tensor
+    tr.bind_image(image.data_ptr())
+
+    def barrier():
+        tr.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...
+        return 1 + rank + step * world
+
+    # ---- untimed: warmup, then a counted pass over the timed iterations (exact node / triangle counts)
+    if args.batch:
+        tr.set_option(pt.PT_OPT_BATCH, args.batch)
+    if args.warmup:
+        tr.trace_range(it_index(0), it_index(args.warmup), world)
+    barrier()
+    tr.reset_stats()
+    tr.clear()
+    tr.set_option(pt.PT_OPT_COUNTERS, 1)
+    count_steps = min(args.steps, 4)
+    tr.trace_range(it_index(args.warmup), it_index(args.warmup + count_steps), world)
+    cs = tr.stats()
+    counted = dict(pb=cs.pathBounces, V=cs.nodesVisited, T=cs.trisTested, H=cs.meshHits,
+                   Vs=cs.shadeNodesVisited, Ts=cs.shadeTrisTested, Hs=cs.shadeMeshHits)
+    tr.set_option(pt.PT_OPT_COUNTERS, 0)
+    tr.reset_stats()
+    tr.clear()
+
+    # ---- timed region: exactly K steps, stage events on the tracer's own stream
+    tr.set_option(pt.PT_OPT_STAGE_TIMING, 1)
+    barrier()
+    t0 = time.perf_counter()
+    tr.trace_range(it_index(args.warmup), it_index(args.warmup + args.steps), world)     # exactly K iterations per rank
+    tr.sync()
+    if world > 1:
+        dist.all_reduce(image)                      # RCCL sum of the W*H*3 accumulation buffers
+    barrier()
+    t1 = time.perf_counter()
+    st = tr.stats()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    pbs = torch.tensor([float(st.pathBounces)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pbs, op=dist.ReduceOp.SUM)
+    elapsed = float(elapsed.item())
+    total_pb = float(pbs.item())
+
+    out = None
+    if rank == 0:
+        value = total_pb / elapsed / 1e6
+        # ---- roofline of the dominant kernel (by accumulated HIP-event time)
+        stages = {"k_intersect": st.msIntersect, "k_shade": st.msShade, "sort": st.msSort, "compact": st.msCompact}
+        per_pb = 1.0 / max(counted["pb"], 1)
+        Vi, Ti, Hi = (counted["V"] - counted["Vs"]) * per_pb, (counted["T"] - counted["Ts"]) * per_pb, (counted["H"] - counted["Hs"]) * per_pb
+        Vs, Ts, Hs = counted["Vs"] * per_pb, counted["Ts"] * per_pb, counted["Hs"] * per_pb
+        # algorithmic bytes per path-bounce = the stage's share of the 192 streaming bytes (path state read and
+        # written once = 96, hit record written and read once = 56, sort key + index written and read once = 16,
+        # image read-modify-write = 24) + 32 B per BVH node visited + 36 B per triangle tested + 64 B of
+        # attributes per mesh hit (none for shadow queries)
+        b_int = 84.0 + 32.0 * Vi + 36.0 * Ti + 64.0 * Hi        # path read 48 + hit written 28 + key/index written 8
+        b_shade = 108.0 + 32.0 * Vs + 36.0 * Ts                 # path written 48 + hit read 28 + key/index read 8 + image 24
+        dominant = "k_intersect" if st.msIntersect >= st.msShade else "k_shade"
+        b_dom = b_int if dominant == "k_intersect" else b_shade
+        ms_dom = stages[dominant]
+        launches = st.launchesIntersect if dominant == "k_intersect" else st.launchesShade
+        units_per_launch = st.pathBounces / max(launches, 1)
+        avg_ms = ms_dom / max(launches, 1)
+        achieved = (b_dom * units_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "alg_bytes_per_path_bounce": round(b_dom, 1), "units_per_launch": round(units_per_launch, 1),
+                    "avg_launch_ms": round(avg_ms, 5),
+                    "nodes_per_path_bounce": round(Vi if dominant == "k_intersect" else Vs, 2),
+                    "tris_per_path_bounce": round(Ti if dominant == "k_intersect" else Ts, 2),
+                    "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stages.items()}}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as orc                    # the checker, timed as the CPU baseline only
+            o = orc.Oracle(pt, sc, orc.MATH_LIBM)
+            c0 = time.perf_counter()
+            for it in range(1, args.cpu_spp + 1):
+                o.trace(it)
+            c1 = time.perf_counter()
+            os_ = o.stats()
+            cpu = {"value": round(os_.pathBounces / (c1 - c0) / 1e6, 4), "unit": "Mpaths*bounce/s", "cores": orc.threads(),
+                   "kind": "port",
+                   "sample": "%d spp of the same workload (%d path-bounces, %.1f s) on the CPU restatement, OpenMP over queue slots"
+                             % (args.cpu_spp, os_.pathBounces, c1 - c0)}
+            o.close()
+
+        out = {"metric": "Mpaths*bounce/s (%s)" % scene_name, "value": round(value, 3), "unit": "Mpaths*bounce/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": desc, "resolution": list(res), "depth": depth, "spp_per_step_per_gpu": 1,
+                          "material_sort": not args.no_sort, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
+                          "path_bounces_per_spp": round(st.pathBounces / max(args.steps, 1), 1)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

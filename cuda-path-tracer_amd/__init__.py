@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmi_pathtrace.so")
 
 PT_SPHERE, PT_CUBE, PT_GLTF_MESH = 0, 1, 2
 PT_DIFFUSE, PT_SPECULAR, PT_REFRACTIVE, PT_PBR, PT_EMITTING = 0, 1, 2, 3, 4
-PT_OPT_MATERIAL_SORT, PT_OPT_USE_BVH, PT_OPT_STAGE_TIMING, PT_OPT_COUNTERS, PT_OPT_USE_GRAPH = 1, 2, 3, 4, 5
+PT_OPT_MATERIAL_SORT, PT_OPT_USE_BVH, PT_OPT_STAGE_TIMING, PT_OPT_COUNTERS, PT_OPT_USE_GRAPH, PT_OPT_BATCH = 1, 2, 3, 4, 5, 6
 PT_MAX_DEPTH = 64
 
 
@@ -93,7 +93,8 @@ class PtStats(C.Structure):
                 ("nodesVisited", C.c_uint64), ("trisTested", C.c_uint64), ("meshHits", C.c_uint64),
                 ("msIntersect", C.c_float), ("msSort", C.c_float), ("msShade", C.c_float),
                 ("msCompact", C.c_float), ("msCamera", C.c_float),
-                ("launchesIntersect", C.c_uint32), ("launchesShade", C.c_uint32)]
+                ("launchesIntersect", C.c_uint32), ("launchesShade", C.c_uint32),
+                ("shadeNodesVisited", C.c_uint64), ("shadeTrisTested", C.c_uint64), ("shadeMeshHits", C.c_uint64)]
 
 
 class PtError(RuntimeError):

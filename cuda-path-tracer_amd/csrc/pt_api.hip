@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -17,12 +19,12 @@ using namespace ptd;
 
 void pt_set_error(const char* fmt, ...);
 
-void ptl_camera(hipStream_t s, const PtCamera& cam, int iter, int depth, PathState st, uint32_t* live);
-void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, int bounce, int sortOn, bool count, void* dc);
-void ptl_sort(hipStream_t s, Queues q, int bounce, int numBuckets);
-void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, int iter, int bounce, int sortOn, bool count, void* dc);
-void ptl_compact(hipStream_t s, Queues q, int bounce, int sortOn);
-void ptl_finish(hipStream_t s, PathState st, Queues q, int depth, void* dc);
+void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q);
+void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
+void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
+void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
+void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
+void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
 void ptl_intersect_rays(hipStream_t s, const SceneView& S, const float* o, const float* d, int n, PtHit* out);
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d);
@@ -36,6 +38,9 @@ void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, floa
             return PT_EHIP;                                                                        \
         }                                                                                          \
     } while (0)
+
+constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
+constexpr int kMaxBatch = 64;
 
 enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_COUNT };
 
@@ -53,10 +58,13 @@ struct PtContext {
     int numPixels = 0;
     bool ownImage = true;
     float* imageOwned = nullptr;
+    float* imageSum = nullptr;          /* the running sum (owned or caller-bound) */
     /* options */
     int sortOn = 1, useBvh = 1, timing = 0, counters = 0;
+    int batch = 0;                      /* iterations the allocated path state can hold */
     /* bookkeeping */
     std::vector<void*> allocs;
+    std::vector<void*> batchAllocs;
     uint64_t iterations = 0;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> freeEvents;
@@ -79,6 +87,50 @@ int devAlloc(PtContext* c, T** out, size_t count)
     }
     c->allocs.push_back(p);
     *out = (T*)p;
+    return PT_OK;
+}
+
+template <typename T>
+int batchAlloc(PtContext* c, T** out, size_t count, bool zero)
+{
+    *out = nullptr;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) {
+        pt_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return PT_ENOMEM;
+    }
+    c->batchAllocs.push_back(p);
+    if (zero && hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { pt_set_error("hipMemset failed"); return PT_EHIP; }
+    *out = (T*)p;
+    return PT_OK;
+}
+
+/* path state, queues and per-iteration contribution buffers for `batch` iterations in flight
+ * (about 116 bytes per pixel and iteration) */
+int allocBatchState(PtContext* c, int batch)
+{
+    for (void* p : c->batchAllocs) (void)hipFree(p);
+    c->batchAllocs.clear();
+    c->batch = 0;
+    const size_t N = (size_t)c->numPixels, B = (size_t)batch;
+    PathState& P = c->state;
+    Queues& Q = c->queues;
+    P.numPixels = N;
+    Q.numPixels = c->numPixels;
+    Q.numBuckets = c->view.numBuckets;
+    Q.numBlocks = (int)((N + kBlock - 1) / kBlock);
+    int rc;
+#define BA(ptr, count, zero) if ((rc = batchAlloc(c, &(ptr), (count), (zero))) != PT_OK) return rc
+    BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
+    BA(P.hitA, N * B, false); BA(P.hitB, N * B, false);
+    BA(P.image, N * B * 3, true);
+    BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);
+    BA(Q.blockHist, (size_t)Q.numBuckets * Q.numBlocks * B, false);
+    BA(Q.blockAlive, (size_t)Q.numBlocks * B, false);
+    BA(Q.live, (size_t)(PT_MAX_DEPTH + 2) * B, true);
+#undef BA
+    c->batch = batch;
     return PT_OK;
 }
 
@@ -133,10 +185,11 @@ void buildEnvCdfs(const PtEnvMap& env, std::vector<float>& marginal, std::vector
 }
 
 struct FlatMesh {
-    std::vector<float4> nodes;     /* 2 per node */
+    std::vector<float4> nodes;     /* 8 per 4-wide node */
     std::vector<float4> hot;       /* 3 per leaf-order triangle */
     std::vector<float4> cold;      /* 4 per leaf-order triangle */
     std::vector<int> leafOfOrig;
+    int depth4 = 0;
     bool hasBvh = false;
 };
 
@@ -149,60 +202,174 @@ void pushTriangle(FlatMesh& fm, const PtTriangle& t, int orig)
     for (int k = 0; k < 3; ++k) { e1[k] = t.v1[k] - t.v0[k]; e2[k] = t.v2[k] - t.v0[k]; }
     fm.hot.push_back(make_float4(t.v0[0], t.v0[1], t.v0[2], e1[0]));
     fm.hot.push_back(make_float4(e1[1], e1[2], e2[0], e2[1]));
-    fm.hot.push_back(make_float4(e2[2], asF(orig), 0.0f, 0.0f));
+    fm.hot.push_back(make_float4(e2[2], asF(orig), asF(0x7fffffff), 0.0f));
     fm.cold.push_back(make_float4(t.n0[0], t.n0[1], t.n0[2], t.n1[0]));
     fm.cold.push_back(make_float4(t.n1[1], t.n1[2], t.n2[0], t.n2[1]));
     fm.cold.push_back(make_float4(t.n2[2], t.uv0[0], t.uv0[1], t.uv1[0]));
     fm.cold.push_back(make_float4(t.uv1[1], t.uv2[0], t.uv2[1], asF(t.materialId)));
 }
 
-/* Re-emit a host BVH (40-byte nodes + index array, src/bvh.h:55-65) in depth-first
- * pre-order with the left child adjacent, leaf triangles contiguous in leaf order. */
+/* Turns the host BVH (40-byte binary nodes + index array, src/bvh.h:55-65) into the device
+ * layout: triangles permuted into leaf order, each stamped with its rank in the reference's
+ * visit order (right subtree first, src/intersections.cu:379-384), and the inner levels
+ * collapsed into 4-wide nodes. */
+struct Flattener {
+    const PtTriangle* tris; int ntri;
+    const PtBvhNode* src; int nsrc;
+    const int32_t* indices; int nidx;
+    FlatMesh& fm;
+    std::vector<int> leafFirst;         /* per source node: first leaf-order triangle */
+    std::vector<char> seen;
+    int error = PT_OK;
+
+    bool check(int i)
+    {
+        if (i < 0 || i >= nsrc) { pt_set_error("BVH child index %d out of range", i); error = PT_EINVAL; return false; }
+        return true;
+    }
+    /* pass 1 (left-first DFS): leaf order; detects cycles and bad ranges */
+    void emitLeaves(int root)
+    {
+        std::vector<std::pair<int, int>> work;
+        work.push_back({ root, 0 });
+        int leafPos = 0;
+        while (!work.empty() && error == PT_OK) {
+            auto [i, depth] = work.back();
+            work.pop_back();
+            if (!check(i)) return;
+            if (seen[i]) { pt_set_error("BVH is not a tree (node %d reached twice)", i); error = PT_EINVAL; return; }
+            if (depth > 62) { pt_set_error("BVH deeper than 62 levels is not supported"); error = PT_ELIMIT; return; }
+            seen[i] = 1;
+            const PtBvhNode& n = src[i];
+            if (n.leftChild == -1) {
+                if (n.triangleCount <= 0 || n.triangleStart < 0 || n.triangleStart + n.triangleCount > nidx) {
+                    pt_set_error("BVH leaf %d has an invalid triangle range", i); error = PT_EINVAL; return;
+                }
+                leafFirst[i] = leafPos;
+                for (int k = 0; k < n.triangleCount; ++k) {
+                    int orig = indices[n.triangleStart + k];
+                    if (orig < 0 || orig >= ntri) { pt_set_error("BVH triangle index out of range"); error = PT_EINVAL; return; }
+                    pushTriangle(fm, tris[orig], orig);
+                    if (fm.leafOfOrig[orig] < 0) fm.leafOfOrig[orig] = leafPos;
+                    ++leafPos;
+                }
+            } else {
+                work.push_back({ n.rightChild, depth + 1 });
+                work.push_back({ n.leftChild, depth + 1 });
+            }
+        }
+    }
+    /* pass 2 (right-first DFS): rank = position in the reference's visit order */
+    void stampRanks(int root)
+    {
+        std::vector<int> work;
+        work.push_back(root);
+        int rank = 0;
+        while (!work.empty()) {
+            int i = work.back();
+            work.pop_back();
+            const PtBvhNode& n = src[i];
+            if (n.leftChild == -1) {
+                for (int k = 0; k < n.triangleCount; ++k) fm.hot[3 * (size_t)(leafFirst[i] + k) + 2].z = asF(rank++);
+            } else {
+                work.push_back(n.leftChild);     /* popped second */
+                work.push_back(n.rightChild);    /* popped first  */
+            }
+        }
+    }
+    static float area(const PtBvhNode& n)
+    {
+        float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    int newNode4()
+    {
+        int id = (int)(fm.nodes.size() / 8);
+        const float big = 3.402823466e+38f;
+        for (int k = 0; k < 3; ++k) fm.nodes.push_back(make_float4(big, big, big, big));
+        for (int k = 0; k < 3; ++k) fm.nodes.push_back(make_float4(-big, -big, -big, -big));
+        fm.nodes.push_back(make_float4(asF(kEmptyRef), asF(kEmptyRef), asF(kEmptyRef), asF(kEmptyRef)));
+        fm.nodes.push_back(make_float4(0, 0, 0, 0));
+        return id;
+    }
+    void setChild(int node4, int slot, const float* bmin, const float* bmax, int ref)
+    {
+        float4* q = &fm.nodes[8 * (size_t)node4];
+        for (int k = 0; k < 3; ++k) { (&q[k].x)[slot] = bmin[k]; (&q[3 + k].x)[slot] = bmax[k]; }
+        (&q[6].x)[slot] = asF(ref);
+    }
+    /* reference to `count` triangles starting at `first`, all under one box; more than 32 triangles
+       (possible only at the builder's depth cap) fan out over extra nodes that repeat the leaf box */
+    int leafRef(int first, int count, const float* bmin, const float* bmax, int depth)
+    {
+        if (count <= kLeafMaxTris) return ~((first << 5) | (count - 1));
+        int id = newNode4();
+        fm.depth4 = std::max(fm.depth4, depth + 1);
+        int per = (count + 3) / 4;
+        per = std::max(per, 1);
+        for (int s = 0, at = 0; s < 4 && at < count; ++s, at += per) {
+            int c = std::min(per, count - at);
+            int r = leafRef(first + at, c, bmin, bmax, depth + 1);
+            setChild(id, s, bmin, bmax, r);
+        }
+        return id;
+    }
+    /* inner source node -> 4-wide node: open the child with the largest box until four slots are used */
+    int collapse(int i, int depth)
+    {
+        int id = newNode4();
+        fm.depth4 = std::max(fm.depth4, depth + 1);
+        int kids[4] = { src[i].leftChild, src[i].rightChild, -1, -1 };
+        int nk = 2;
+        while (nk < 4) {
+            int pick = -1;
+            float bestA = -1.0f;
+            for (int k = 0; k < nk; ++k)
+                if (src[kids[k]].leftChild != -1 && area(src[kids[k]]) > bestA) { bestA = area(src[kids[k]]); pick = k; }
+            if (pick < 0) break;
+            int c = kids[pick];
+            for (int k = nk; k > pick + 1; --k) kids[k] = kids[k - 1];
+            kids[pick] = src[c].leftChild;
+            kids[pick + 1] = src[c].rightChild;
+            ++nk;
+        }
+        for (int k = 0; k < nk; ++k) {
+            const PtBvhNode& c = src[kids[k]];
+            int ref = (c.leftChild == -1) ? leafRef(leafFirst[kids[k]], c.triangleCount, c.bmin, c.bmax, depth + 1)
+                                          : collapse(kids[k], depth + 1);
+            setChild(id, k, c.bmin, c.bmax, ref);
+        }
+        return id;
+    }
+};
+
 int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nnodes, const int32_t* indices, int nidx,
                 FlatMesh& fm)
 {
     fm.leafOfOrig.assign(std::max(ntri, 1), -1);
     if (ntri == 0 || nnodes == 0) { fm.hasBvh = false; return PT_OK; }
-    struct Item { int src; int depth; int parentSlot; };
-    std::vector<Item> work;
-    work.push_back({ 0, 0, -1 });
-    int emitted = 0;
-    int leafPos = 0;
-    while (!work.empty()) {
-        Item it = work.back();
-        work.pop_back();
-        if (it.src < 0 || it.src >= nnodes) { pt_set_error("BVH child index %d out of range", it.src); return PT_EINVAL; }
-        if (emitted >= nnodes) { pt_set_error("BVH is not a tree (node visited twice)"); return PT_EINVAL; }
-        if (it.depth >= kStackDepth) { pt_set_error("BVH deeper than %d levels is not supported", kStackDepth - 1); return PT_ELIMIT; }
-        const PtBvhNode& n = nodes[it.src];
-        int self = emitted++;
-        if (it.parentSlot >= 0) fm.nodes[2 * (size_t)it.parentSlot].w = asF(self);   /* this is the parent's right child */
-        if (n.leftChild == -1) {
-            if (n.triangleCount <= 0 || n.triangleStart < 0 || n.triangleStart + n.triangleCount > nidx) {
-                pt_set_error("BVH leaf with invalid triangle range");
-                return PT_EINVAL;
-            }
-            fm.nodes.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], asF(leafPos)));
-            fm.nodes.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], asF(n.triangleCount)));
-            for (int i = 0; i < n.triangleCount; ++i) {
-                int orig = indices[n.triangleStart + i];
-                if (orig < 0 || orig >= ntri) { pt_set_error("BVH triangle index out of range"); return PT_EINVAL; }
-                pushTriangle(fm, tris[orig], orig);
-                if (fm.leafOfOrig[orig] < 0) fm.leafOfOrig[orig] = leafPos;
-                ++leafPos;
-            }
-        } else {
-            fm.nodes.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], asF(-1)));
-            fm.nodes.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], asF(0)));
-            /* right is emitted after the whole left subtree: push right first, then left */
-            work.push_back({ n.rightChild, it.depth + 1, self });
-            work.push_back({ n.leftChild, it.depth + 1, -1 });
-        }
-    }
+    if (ntri >= (1 << 26)) { pt_set_error("meshes are limited to %d triangles", (1 << 26) - 1); return PT_ELIMIT; }
+    Flattener F{ tris, ntri, nodes, nnodes, indices, nidx, fm, std::vector<int>(nnodes, -1), std::vector<char>(nnodes, 0) };
+    F.emitLeaves(0);
+    if (F.error != PT_OK) return F.error;
+    F.stampRanks(0);
     /* triangles no leaf references (possible only with a caller-supplied BVH) stay reachable
        for the linear fallback */
+    int leafPos = (int)(fm.hot.size() / 3);
     for (int i = 0; i < ntri; ++i)
         if (fm.leafOfOrig[i] < 0) { pushTriangle(fm, tris[i], i); fm.leafOfOrig[i] = leafPos++; }
+    if (nodes[0].leftChild == -1) {
+        int id = F.newNode4();
+        fm.depth4 = 1;
+        F.setChild(id, 0, nodes[0].bmin, nodes[0].bmax, F.leafRef(F.leafFirst[0], nodes[0].triangleCount, nodes[0].bmin, nodes[0].bmax, 1));
+    } else {
+        F.collapse(0, 0);
+    }
+    /* every visit pushes at most three entries */
+    if (3 * fm.depth4 + 1 > kLdsStack + kOverflowStack) {
+        pt_set_error("BVH too deep for the traversal stack (%d wide levels)", fm.depth4);
+        return PT_ELIMIT;
+    }
     fm.hasBvh = true;
     return PT_OK;
 }
@@ -251,6 +418,7 @@ int pt_destroy(PtContext* c)
     resolveSpans(c);
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
     for (void* p : c->allocs) (void)hipFree(p);
+    for (void* p : c->batchAllocs) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -319,7 +487,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
             rc = flattenMesh(pm.triangles, pm.triangleCount, nodes, nn, idx, ni, fm);
             if (built) pt_bvh_free(built);
             if (rc != PT_OK) { pt_destroy(c); return rc; }
-            G.nodeStart = (int)(allNodes.size() / 2);
+            G.nodeStart = (int)(allNodes.size() / 8);
             G.triStart = (int)(allHot.size() / 3);
             G.triCount = pm.triangleCount;
             G.hasBvh = fm.hasBvh ? 1 : 0;
@@ -388,21 +556,17 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     V.envTotalPower = totalPower;
     V.numBuckets = d->materialCount + 1;
 
-    /* ---- path state, queues, image */
+    /* ---- running sum, path state and queues */
     const size_t N = (size_t)c->numPixels;
-    PathState& P = c->state;
-    TRY_RC(devAlloc(c, &P.rayO, N)); TRY_RC(devAlloc(c, &P.rayD, N)); TRY_RC(devAlloc(c, &P.col, N));
-    TRY_RC(devAlloc(c, &P.hitA, N)); TRY_RC(devAlloc(c, &P.hitB, N));
     TRY_RC(devAlloc(c, &c->imageOwned, N * 3));
-    P.image = c->imageOwned;
-    TRY_HIP(hipMemset(P.image, 0, N * 3 * sizeof(float)));
-    Queues& Q = c->queues;
-    Q.numBlocks = (int)((N + kBlock - 1) / kBlock);
-    TRY_RC(devAlloc(c, &Q.q0, N)); TRY_RC(devAlloc(c, &Q.q1, N)); TRY_RC(devAlloc(c, &Q.keys, N));
-    TRY_RC(devAlloc(c, &Q.blockHist, (size_t)V.numBuckets * Q.numBlocks));
-    TRY_RC(devAlloc(c, &Q.blockAlive, (size_t)Q.numBlocks));
-    TRY_RC(devAlloc(c, &Q.live, (size_t)PT_MAX_DEPTH + 2));
-    TRY_HIP(hipMemset(Q.live, 0, (PT_MAX_DEPTH + 2) * sizeof(uint32_t)));
+    c->imageSum = c->imageOwned;
+    TRY_HIP(hipMemset(c->imageSum, 0, N * 3 * sizeof(float)));
+    {
+        const char* e = getenv("PT_BATCH");
+        int batch = e ? atoi(e) : kDefaultBatch;
+        batch = std::max(1, std::min(batch, kMaxBatch));
+        TRY_RC(allocBatchState(c, batch));
+    }
     TRY_RC(devAlloc(c, &c->dc, 1));
     TRY_HIP(hipMemset(c->dc, 0, sizeof(DevCounters)));
     TRY_HIP(hipDeviceSynchronize());
@@ -412,33 +576,43 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     return PT_OK;
 }
 
-int pt_trace(PtContext* c, int iter)
+static int traceBatch(PtContext* c, Batch bt)
 {
-    if (!c) { pt_set_error("pt_trace: null context"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     SceneView V = c->view;
     V.useBvh = c->useBvh;
     const bool count = c->counters != 0;
-    { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, iter, c->traceDepth, c->state, c->queues.live); }
+    { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, bt, c->traceDepth, c->state, c->queues); }
     for (int b = 0; b < c->traceDepth; ++b) {
-        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, b, c->sortOn, count, c->dc); }
-        if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, b, V.numBuckets); }
-        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, iter, b, c->sortOn, count, c->dc); }
-        { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, b, c->sortOn); }
+        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, bt, b, c->sortOn, count, c->dc); }
+        if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, bt, b, V.numBuckets); }
+        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, c->dc); }
+        { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, bt, b, c->sortOn); }
     }
-    ptl_finish(s, c->state, c->queues, c->traceDepth, c->dc);
+    ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc);
     HIP_TRY(hipGetLastError());
-    c->iterations++;
+    c->iterations += (uint64_t)bt.count;
     return PT_OK;
+}
+
+int pt_trace(PtContext* c, int iter)
+{
+    if (!c) { pt_set_error("pt_trace: null context"); return PT_EINVAL; }
+    Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
+    return traceBatch(c, bt);
 }
 
 int pt_trace_range(PtContext* c, int iter_begin, int iter_end, int iter_stride)
 {
     if (!c || iter_stride <= 0) { pt_set_error("pt_trace_range: bad argument"); return PT_EINVAL; }
-    for (int it = iter_begin; it < iter_end; it += iter_stride) {
-        int rc = pt_trace(c, it);
+    /* iterations are independent given their index: up to `batch` of them share every launch */
+    for (int it = iter_begin; it < iter_end;) {
+        int remaining = (iter_end - it + iter_stride - 1) / iter_stride;
+        Batch bt; bt.count = std::min(remaining, c->batch); bt.iterBase = it; bt.iterStride = iter_stride;
+        int rc = traceBatch(c, bt);
         if (rc != PT_OK) return rc;
+        it += bt.count * iter_stride;
     }
     return PT_OK;
 }
@@ -456,7 +630,7 @@ int pt_display(PtContext* c, int iter, uint8_t* dev_rgba)
 {
     if (!c || !dev_rgba || iter <= 0) { pt_set_error("pt_display: bad argument"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
-    ptl_display(c->stream, c->state.image, c->numPixels, iter, dev_rgba);
+    ptl_display(c->stream, c->imageSum, c->numPixels, iter, dev_rgba);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -466,7 +640,7 @@ int pt_download(PtContext* c, float* host_rgb)
     if (!c || !host_rgb) { pt_set_error("pt_download: null argument"); return PT_EINVAL; }
     int rc = pt_sync(c);
     if (rc != PT_OK) return rc;
-    HIP_TRY(hipMemcpy(host_rgb, c->state.image, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_rgb, c->imageSum, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -475,7 +649,7 @@ int pt_bind_image(PtContext* c, float* dev_rgb)
     if (!c) { pt_set_error("pt_bind_image: null context"); return PT_EINVAL; }
     int rc = pt_sync(c);
     if (rc != PT_OK) return rc;
-    c->state.image = dev_rgb ? dev_rgb : c->imageOwned;
+    c->imageSum = dev_rgb ? dev_rgb : c->imageOwned;
     c->ownImage = dev_rgb == nullptr;
     return PT_OK;
 }
@@ -485,7 +659,7 @@ int pt_upload_image(PtContext* c, const float* host_rgb)
     if (!c || !host_rgb) { pt_set_error("pt_upload_image: null argument"); return PT_EINVAL; }
     int rc = pt_sync(c);
     if (rc != PT_OK) return rc;
-    HIP_TRY(hipMemcpy(c->state.image, host_rgb, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->imageSum, host_rgb, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyHostToDevice));
     return PT_OK;
 }
 
@@ -493,7 +667,7 @@ int pt_clear(PtContext* c)
 {
     if (!c) { pt_set_error("pt_clear: null context"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->state.image, 0, (size_t)c->numPixels * 3 * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->imageSum, 0, (size_t)c->numPixels * 3 * sizeof(float), c->stream));
     return PT_OK;
 }
 
@@ -506,6 +680,12 @@ int pt_set_option(PtContext* c, int option, int value)
     case PT_OPT_STAGE_TIMING: { int rc = pt_sync(c); if (rc != PT_OK) return rc; c->timing = value ? 1 : 0; break; }
     case PT_OPT_COUNTERS: c->counters = value ? 1 : 0; break;
     case PT_OPT_USE_GRAPH: break;      /* accepted; launches are always direct in this build */
+    case PT_OPT_BATCH: {
+        if (value < 1 || value > kMaxBatch) { pt_set_error("pt_set_option: batch must be in [1,%d]", kMaxBatch); return PT_ELIMIT; }
+        int rc = pt_sync(c); if (rc != PT_OK) return rc;
+        if (value != c->batch) { rc = allocBatchState(c, value); if (rc != PT_OK) return rc; }
+        break;
+    }
     default: pt_set_error("pt_set_option: unknown option %d", option); return PT_EINVAL;
     }
     return PT_OK;
@@ -526,7 +706,11 @@ int pt_stats(PtContext* c, PtStats* out)
     for (int b = 0; b <= c->traceDepth && b < PT_MAX_DEPTH; ++b) out->lastLive[b] = h.lastLive[b];
     for (int b = 1; b <= c->traceDepth; ++b) if (h.lastLive[b] == 0) { depth = (uint32_t)b; break; }
     out->lastDepth = c->iterations ? depth : 0;
-    out->nodesVisited = h.nodes; out->trisTested = h.tris; out->meshHits = h.meshHits;
+    out->nodesVisited = h.trav[0][0] + h.trav[1][0];
+    out->trisTested = h.trav[0][1] + h.trav[1][1];
+    out->meshHits = h.trav[0][2] + h.trav[1][2];
+    if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] per-ray max: intersect nodes %u tris %u | shade nodes %u tris %u\n", h.maxNodes[0], h.maxTris[0], h.maxNodes[1], h.maxTris[1]);
+    out->shadeNodesVisited = h.trav[1][0]; out->shadeTrisTested = h.trav[1][1]; out->shadeMeshHits = h.trav[1][2];
     out->msCamera = c->ms[ST_CAMERA]; out->msIntersect = c->ms[ST_INTERSECT]; out->msSort = c->ms[ST_SORT];
     out->msShade = c->ms[ST_SHADE]; out->msCompact = c->ms[ST_COMPACT];
     out->launchesIntersect = c->launches[ST_INTERSECT]; out->launchesShade = c->launches[ST_SHADE];
@@ -579,7 +763,8 @@ int pt_camera_rays(PtContext* c, int iter, float* origins, float* directions)
     float *dO = nullptr, *dD = nullptr;
     HIP_TRY(hipMalloc((void**)&dO, (size_t)n * 12));
     if (hipMalloc((void**)&dD, (size_t)n * 12) != hipSuccess) { (void)hipFree(dO); pt_set_error("pt_camera_rays: out of device memory"); return PT_ENOMEM; }
-    ptl_camera(c->stream, c->cam, iter, c->traceDepth, c->state, c->queues.live);
+    Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
+    ptl_camera(c->stream, c->cam, bt, c->traceDepth, c->state, c->queues);
     ptl_export_rays(c->stream, c->state, n, dO, dD);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(origins, dO, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);

@@ -24,19 +24,21 @@ namespace ptd {
 PT_DEV int laneId() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 PT_DEV unsigned long long laneMaskLt() { return (1ull << laneId()) - 1ull; }
 
-PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc)
+PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 {
     /* one atomic per wave and counter */
     unsigned n = c.nodes, t = c.tris, h = c.meshHits;
+    atomicMax(&dc->maxNodes[stage], n);
+    atomicMax(&dc->maxTris[stage], t);
     for (int off = 32; off > 0; off >>= 1) {
         n += __shfl_down(n, off);
         t += __shfl_down(t, off);
         h += __shfl_down(h, off);
     }
     if (laneId() == 0) {
-        if (n) atomicAdd(&dc->nodes, (unsigned long long)n);
-        if (t) atomicAdd(&dc->tris, (unsigned long long)t);
-        if (h) atomicAdd(&dc->meshHits, (unsigned long long)h);
+        if (n) atomicAdd(&dc->trav[stage][0], (unsigned long long)n);
+        if (t) atomicAdd(&dc->trav[stage][1], (unsigned long long)t);
+        if (h) atomicAdd(&dc->trav[stage][2], (unsigned long long)h);
     }
 }
 
@@ -44,8 +46,11 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc)
  * One thread per pixel: 2x2 stratified jitter cell = iter % 4, two draws from the
  * (iter, pixel, 0) stream, pinhole direction (generateRayFromCamera,
  * src/pathtrace.cu:694-745). */
-__global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, int iter, int traceDepth, PathState st, uint32_t* live)
+__global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int traceDepth, PathState st, Queues q)
 {
+    st = st.at(blockIdx.y);
+    uint32_t* live = q.at(blockIdx.y).live;
+    const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
     const int W = cam.resolution[0], H = cam.resolution[1];
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index == 0) live[0] = (uint32_t)(W * H);
@@ -73,6 +78,8 @@ __global__ void __launch_bounds__(kBlock) k_intersect(SceneView S, PathState st,
 {
     __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ int s_hist[kMaxBuckets];
+    st = st.at(blockIdx.y);
+    q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
     const int slot = blockIdx.x * kBlock + tid;
@@ -97,7 +104,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect(SceneView S, PathState st,
         key = (h.t > 0.0f) ? h.mat : (nb - 1);
         if (sortOn) q.keys[slot] = key;
     }
-    if (COUNT) flushCounters(cnt, dc);
+    if (COUNT) flushCounters(cnt, dc, 0);
     if (sortOn) {
         /* wave-aggregated histogram: one LDS atomic per distinct bucket per wave */
         unsigned long long todo = __ballot(active);
@@ -149,6 +156,7 @@ PT_DEV int blockExclusiveScan1024(int v, int* s_wave, int* total)
 __global__ void __launch_bounds__(1024) k_sort_scan(Queues q, int bounce, int numBuckets)
 {
     __shared__ int s_wave[17];
+    q = q.at(blockIdx.y);
     const uint32_t n = q.live[bounce];
     if (n == 0) return;
     const int nbAct = (int)((n + kBlock - 1) / kBlock);
@@ -184,6 +192,7 @@ __global__ void __launch_bounds__(1024) k_sort_scan(Queues q, int bounce, int nu
 __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, int numBuckets)
 {
     __shared__ int s_waveCnt[(kBlock / 64) * kMaxBuckets];
+    q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
     if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
@@ -215,10 +224,13 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, i
 
 /* ------------------------------------------------------------------- shade */
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Queues q, int iter, int bounce, int sortOn, DevCounters* dc)
+__global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Queues q, Batch bt, int bounce, int sortOn, DevCounters* dc)
 {
     __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ int s_alive[kBlock / 64];
+    st = st.at(blockIdx.y);
+    q = q.at(blockIdx.y);
+    const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
     if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
@@ -250,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Que
         }
         queue[slot] = alive ? pix : (-1 - pix);
     }
-    if (COUNT) flushCounters(cnt, dc);
+    if (COUNT) flushCounters(cnt, dc, 1);
     unsigned long long m = __ballot(alive);
     if (laneId() == 0) s_alive[tid >> 6] = (int)__builtin_popcountll(m);
     __syncthreads();
@@ -266,6 +278,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Que
 __global__ void __launch_bounds__(1024) k_compact_scan(Queues q, int bounce)
 {
     __shared__ int s_wave[17];
+    q = q.at(blockIdx.y);
     const uint32_t n = q.live[bounce];
     const int nbAct = (int)((n + kBlock - 1) / kBlock);
     int carry = 0;
@@ -285,6 +298,7 @@ __global__ void __launch_bounds__(1024) k_compact_scan(Queues q, int bounce)
 __global__ void __launch_bounds__(kBlock) k_compact_scatter(Queues q, int bounce, int sortOn)
 {
     __shared__ int s_cnt[kBlock / 64];
+    q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
     if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
@@ -305,6 +319,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_scatter(Queues q, int bounce
 /* unsorted mode compacts q0 -> q1; copy back so q0 is always the input of the next bounce */
 __global__ void __launch_bounds__(kBlock) k_copy_queue(Queues q, int bounce)
 {
+    q = q.at(blockIdx.y);
     const uint32_t n = q.live[bounce + 1];
     const int slot = blockIdx.x * kBlock + threadIdx.x;
     if ((uint32_t)slot < n) q.q0[slot] = q.q1[slot];
@@ -313,6 +328,8 @@ __global__ void __launch_bounds__(kBlock) k_copy_queue(Queues q, int bounce)
 /* finalGather (src/pathtrace.cu:2630-2639): survivors of the last bounce, normally none */
 __global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q, int depth)
 {
+    st = st.at(blockIdx.y);
+    q = q.at(blockIdx.y);
     const uint32_t n = q.live[depth];
     const int slot = blockIdx.x * kBlock + threadIdx.x;
     if ((uint32_t)slot >= n) return;
@@ -322,19 +339,37 @@ __global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q,
     im[0] += c.x; im[1] += c.y; im[2] += c.z;
 }
 
-/* per-iteration bookkeeping: path-bounce total and a snapshot of the live curve */
-__global__ void k_finish(Queues q, int depth, DevCounters* dc)
+/* per-batch bookkeeping: path-bounce total over the batch, live curve of its last iteration */
+__global__ void k_finish(Queues q0, int depth, int batch, DevCounters* dc)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long s = 0;
-    for (int b = 0; b < depth; ++b) {
-        uint32_t v = q.live[b];
-        dc->lastLive[b] = v;
-        s += v;
-        if (v == 0) { for (int k = b + 1; k <= depth; ++k) dc->lastLive[k] = 0; break; }
+    for (int k = 0; k < batch; ++k) {
+        Queues q = q0.at(k);
+        for (int b = 0; b < depth; ++b) {
+            uint32_t v = q.live[b];
+            s += v;
+            if (v == 0) break;
+        }
+        if (k == batch - 1)
+            for (int b = 0; b <= depth; ++b) dc->lastLive[b] = q.live[b];
     }
-    dc->lastLive[depth] = q.live[depth];
     dc->pathBounces += s;
+}
+
+/* image += contribution of iteration 0, then 1, ... : the order one-iteration-at-a-time accumulation
+ * would add them in (at most one contribution per pixel and iteration); contributions are re-zeroed */
+__global__ void __launch_bounds__(kBlock) k_accumulate(float* image, float* partial, size_t n3, int batch)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n3) return;
+    float acc = image[i];
+    for (int k = 0; k < batch; ++k) {
+        float v = partial[(size_t)k * n3 + i];
+        acc += v;
+        partial[(size_t)k * n3 + i] = 0.0f;
+    }
+    image[i] = acc;
 }
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): (int)(sum / iter * 255.0) with a double 255.0 */
@@ -407,35 +442,37 @@ static inline int gridFor(long long n) { return (int)((n + kBlock - 1) / kBlock)
 
 extern "C++" {
 
-void ptl_camera(hipStream_t s, const PtCamera& cam, int iter, int depth, PathState st, uint32_t* live)
+void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q)
 {
-    hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1])), dim3(kBlock), 0, s, cam, iter, depth, st, live);
+    hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1]), bt.count), dim3(kBlock), 0, s, cam, bt, depth, st, q);
 }
-void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, int bounce, int sortOn, bool count, void* dc)
+void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc)
 {
-    if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_intersect<false>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_intersect<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
 }
-void ptl_sort(hipStream_t s, Queues q, int bounce, int numBuckets)
+void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
 {
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, q, bounce, numBuckets);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks), dim3(kBlock), 0, s, q, bounce, numBuckets);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1, bt.count), dim3(1024), 0, s, q, bounce, numBuckets);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, numBuckets);
 }
-void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, int iter, int bounce, int sortOn, bool count, void* dc)
+void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc)
 {
-    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, iter, bounce, sortOn, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks), dim3(kBlock), 0, s, S, st, q, iter, bounce, sortOn, (DevCounters*)dc);
+    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, (DevCounters*)dc);
 }
-void ptl_compact(hipStream_t s, Queues q, int bounce, int sortOn)
+void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
 {
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, q, bounce);
-    hipLaunchKernelGGL(k_compact_scatter, dim3(q.numBlocks), dim3(kBlock), 0, s, q, bounce, sortOn);
-    if (!sortOn) hipLaunchKernelGGL(k_copy_queue, dim3(q.numBlocks), dim3(kBlock), 0, s, q, bounce);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1, bt.count), dim3(1024), 0, s, q, bounce);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, sortOn);
+    if (!sortOn) hipLaunchKernelGGL(k_copy_queue, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce);
 }
-void ptl_finish(hipStream_t s, PathState st, Queues q, int depth, void* dc)
+void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc)
 {
-    hipLaunchKernelGGL(k_final_gather, dim3(q.numBlocks), dim3(kBlock), 0, s, st, q, depth);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, (DevCounters*)dc);
+    hipLaunchKernelGGL(k_final_gather, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, st, q, depth);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, bt.count, (DevCounters*)dc);
+    const size_t n3 = 3 * st.numPixels;
+    hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, bt.count);
 }
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba)
 {

@@ -13,11 +13,13 @@
  *                material and compaction permute that queue, never the 80 bytes of
  *                state.  A queue slot index plays the role of the array index the
  *                reference seeds its RNG with (src/pathtrace.cu:2483-2484).
- *   BVH nodes    32 bytes, two float4:  (bmin.xyz, a) (bmax.xyz, b)
- *                  inner: a = right child, b = 0   (left child is node+1: pre-order)
- *                  leaf : a = first triangle (leaf order), b = count > 0
+ *   BVH nodes    4-wide, 128 bytes = one cache line = eight float4, child boxes SoA:
+ *                  minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] (pad)
+ *                  ref >= 0: child node;  ref < 0: leaf, ~ref = first triangle << 5 | count-1;
+ *                  ref == kEmptyRef: unused slot.  The node set is the host builder's binary
+ *                  tree with inner levels collapsed; every leaf keeps the host tree's box.
  *   triangles    stored in LEAF ORDER so a leaf's triangles are contiguous:
- *                  hot  48 bytes: (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig index, -, -)
+ *                  hot  48 bytes: (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig index, visit rank, -)
  *                  cold 64 bytes: n0 n1 n2 uv0 uv1 uv2 materialId (fetched once per hit)
  */
 #pragma once
@@ -27,7 +29,11 @@
 namespace ptd {
 
 constexpr int kBlock = 256;          /* threads per workgroup of every 1-D kernel (4 waves) */
-constexpr int kStackDepth = 32;      /* per-ray traversal stack entries held in LDS          */
+constexpr int kLdsStack = 16;        /* traversal stack entries (ref + entry distance) per ray held in LDS */
+constexpr int kStackDepth = 2 * kLdsStack; /* LDS dwords per lane                                    */
+constexpr int kOverflowStack = 64;   /* further entries per ray in private memory, touched only past kLdsStack */
+constexpr int kEmptyRef = 0x7fffffff;
+constexpr int kLeafMaxTris = 32;     /* triangles addressable by one leaf reference            */
 constexpr int kMaxBuckets = 256;     /* material ids + the miss bucket handled by the sort   */
 
 struct DGeom {
@@ -60,13 +66,24 @@ struct SceneView {
     int numBuckets;                 /* numMaterials + 1 */
 };
 
+/* Several iterations ("a batch") run through the same launches, one grid row (blockIdx.y) each.
+ * Every iteration owns a full copy of the path state and of the queues, so slot numbering, sort
+ * and compaction stay per iteration; at(k) selects iteration k's copy. */
 struct PathState {
     float4* rayO;
     float4* rayD;
     float4* col;
     float4* hitA;
     float4* hitB;
-    float* image;                   /* W*H*3 running sum */
+    float* image;                   /* W*H*3: this iteration's contribution inside the kernels */
+    size_t numPixels;
+    PT_DEV PathState at(int k) const
+    {
+        PathState r = *this;
+        const size_t off = (size_t)k * numPixels;
+        r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.image += 3 * off;
+        return r;
+    }
 };
 
 struct Queues {
@@ -77,10 +94,26 @@ struct Queues {
     int* blockAlive;    /* [numBlocks] survivors per workgroup, scanned in place         */
     uint32_t* live;     /* [PT_MAX_DEPTH + 2] live paths entering bounce b               */
     int numBlocks;      /* ceil(N / kBlock)                                              */
+    int numPixels;
+    int numBuckets;
+    PT_DEV Queues at(int k) const
+    {
+        Queues r = *this;
+        const size_t off = (size_t)k * numPixels;
+        r.q0 += off; r.q1 += off; r.keys += off;
+        r.blockHist += (size_t)k * numBuckets * numBlocks;
+        r.blockAlive += (size_t)k * numBlocks;
+        r.live += (size_t)k * (PT_MAX_DEPTH + 2);
+        return r;
+    }
 };
 
+struct Batch { int count; int iterBase; int iterStride; };
+
 struct DevCounters {
-    unsigned long long pathBounces, nodes, tris, meshHits;
+    unsigned long long pathBounces;
+    unsigned long long trav[2][3];      /* [0] intersect stage, [1] shade stage: nodes, triangles, mesh hits */
+    unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
     uint32_t lastLive[PT_MAX_DEPTH + 2];
 };
 
@@ -177,12 +210,22 @@ PT_DEV float hitTriangle(const float4* hot, F3 lo, F3 ld, F3& bary)
     return -1.0f;
 }
 
-/* Closest hit of one mesh.  Visits nodes in the order the reference's stack loop does
- * (src/intersections.cu:344-386: left pushed, right pushed, right popped first) so that
- * exact-distance ties resolve to the same triangle: descend into the right child, keep
- * the left child (node+1) on the per-lane LDS stack.  stack points at this lane's column
- * of a [kStackDepth][kBlock] LDS array.  Returns world distance or -1; attributes are
- * fetched only when wantAttr (shadow queries need t alone). */
+/* Closest hit of one mesh.
+ *
+ * The reference walks a binary tree with an explicit stack, right child first, no near/far
+ * order, one 40-byte node per dependent fetch (src/intersections.cu:344-386).  What that loop
+ * computes is order-independent except for exact-distance ties: the closest of all triangles
+ * whose LEAF box passes the slab test, the first-visited one among equals (strict '<').
+ * Ancestor boxes only accelerate: slab intervals of nested boxes nest in IEEE arithmetic
+ * (subtraction and multiplication by the same 1/d are monotone), so a ray that passes a leaf
+ * box passes every ancestor.  This traversal therefore uses its own structure above the
+ * leaves (4-wide nodes, nearest child first, entry distance kept on the stack for pruning at
+ * pop time) and reproduces the reference's choice among equals with a per-triangle visit rank
+ * computed on the host from the reference's order.
+ *
+ * stack: this lane's column of a [kStackDepth][kBlock] LDS array (refs in rows 0..kLdsStack-1,
+ * entry distances in the rows above); deeper entries spill to private memory.
+ * Returns world distance or -1; attributes are fetched only when wantAttr. */
 template <bool COUNT>
 PT_DEV float hitMesh(const SceneView& S, const DGeom& g, const Ray& r, int* stack, bool wantAttr,
                      F3& N, F2& uv, int& mat, int& triOrig, TravCounters& cnt)
@@ -191,41 +234,77 @@ PT_DEV float hitMesh(const SceneView& S, const DGeom& g, const Ray& r, int* stac
     F3 ld = normalize(mulMV(g.I, r.d, 0.0f));
     float closestT = 3.402823466e+38f;
     int best = -1;
+    int bestRank = 0x7fffffff;
     F3 bestBary = f3(0.0f);
     const float4* hot = S.triHot + 3 * (size_t)g.triStart;
 
     if (S.useBvh && g.hasBvh) {
-        F3 invDir = 1.0f / ld;
-        const float4* nodes = S.nodes + 2 * (size_t)g.nodeStart;
+        const F3 invDir = 1.0f / ld;
+        const float4* nodes = S.nodes + 8 * (size_t)g.nodeStart;
+        const float INF = __builtin_inff();
+        int ovRef[kOverflowStack];
+        float ovT[kOverflowStack];
         int sp = 0;
-        int node = 0;
+        int ref = 0;
         while (true) {
-            float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
-            if (COUNT) cnt.nodes++;
-            F3 t0 = (f3(n0.x, n0.y, n0.z) - lo) * invDir;
-            F3 t1 = (f3(n1.x, n1.y, n1.z) - lo) * invDir;
-            F3 tlo = vmin(t0, t1);
-            F3 thi = vmax(t0, t1);
-            float tMin = selMax(selMax(tlo.x, tlo.y), tlo.z);
-            float tMax = selMin(selMin(thi.x, thi.y), thi.z);
-            bool enter = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);
-            int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
-            if (enter && b == 0) {              /* inner node */
-                if (sp < kStackDepth) { stack[sp * kBlock] = node + 1; sp++; }
-                node = a;
-                continue;
-            }
-            if (enter) {                        /* leaf */
-                for (int i = 0; i < b; ++i) {
+            if (ref >= 0) {
+                const float4* q = nodes + 8 * (size_t)ref;
+                float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+                float4 rf = q[6];
+                if (COUNT) cnt.nodes++;
+                float tk[4];
+                int rk[4];
+#define PT_CHILD(k, C)                                                                              \
+                {                                                                                    \
+                    float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;           \
+                    float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;           \
+                    float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;           \
+                    float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1)); \
+                    float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1)); \
+                    int cr = __float_as_int(rf.C);                                                   \
+                    bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT); \
+                    tk[k] = in ? tMin : INF;                                                         \
+                    rk[k] = cr;                                                                      \
+                }
+                PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
+#undef PT_CHILD
+                /* nearest first: 5-exchange network on (distance, ref) */
+#define PT_CSWAP(i, j) { bool sw = tk[j] < tk[i]; float tt_ = sw ? tk[j] : tk[i]; float tu_ = sw ? tk[i] : tk[j]; \
+                         int ra_ = sw ? rk[j] : rk[i]; int rb_ = sw ? rk[i] : rk[j]; tk[i] = tt_; tk[j] = tu_; rk[i] = ra_; rk[j] = rb_; }
+                PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+#define PT_PUSH(k)                                                                                   \
+                if (tk[k] < INF) {                                                                   \
+                    if (sp < kLdsStack) { stack[sp * kBlock] = rk[k]; stack[(kLdsStack + sp) * kBlock] = __float_as_int(tk[k]); sp++; } \
+                    else if (sp < kLdsStack + kOverflowStack) { ovRef[sp - kLdsStack] = rk[k]; ovT[sp - kLdsStack] = tk[k]; sp++; }     \
+                }
+                PT_PUSH(3) PT_PUSH(2) PT_PUSH(1)
+#undef PT_PUSH
+                if (tk[0] < INF) { ref = rk[0]; continue; }
+            } else {
+                const unsigned x = ~(unsigned)ref;
+                const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
+                for (int i = 0; i < count; ++i) {
                     F3 bary;
-                    float tt = hitTriangle(hot + 3 * (size_t)(a + i), lo, ld, bary);
+                    const float4* tp = hot + 3 * (size_t)(first + i);
+                    float tt = hitTriangle(tp, lo, ld, bary);
                     if (COUNT) cnt.tris++;
-                    if (tt > 0.0f && tt < closestT) { closestT = tt; bestBary = bary; best = a + i; }
+                    if (tt > 0.0f && !(tt > closestT)) {
+                        int rank = __float_as_int(tp[2].z);
+                        if (tt < closestT || rank < bestRank) { closestT = tt; bestBary = bary; best = first + i; bestRank = rank; }
+                    }
                 }
             }
-            if (sp == 0) break;
-            sp--;
-            node = stack[sp * kBlock];
+            /* pop the next entry that can still hold a closer (or equal) hit */
+            bool found = false;
+            while (sp > 0) {
+                sp--;
+                float t;
+                if (sp < kLdsStack) { ref = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]); }
+                else { ref = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack]; }
+                if (!(t > closestT)) { found = true; break; }
+            }
+            if (!found) break;
         }
     } else {
         /* linear scan in ORIGINAL triangle order (meshIntersectionTest, src/intersections.cu:168-245) */

@@ -323,9 +323,9 @@ def make_scene(name, res=None, depth=None, directory=None, tex_size=1024, env_si
         M = build_transforms(*trs)[0].T.astype(np.float64)
         M2 = M @ M
         s2 = abs(np.linalg.det(M2[:3, :3])) ** (1.0 / 3.0)
-        centre = np.linalg.solve(M2, np.array([0.0, 4.2, 0.0, 1.0]))[:3]
+        centre = np.linalg.solve(M2, np.array([0.0, 5.0, 0.0, 1.0]))[:3]
         tris = blob_mesh(g[0], g[1], seed=1, trs=trs, material_ids=ids, center=tuple(centre), squash=(1.25, 1.0, 0.8),
-                         radius=3.0 / s2)
+                         radius=5.5 / s2, bumps=10, amplitude=0.45)
         sc.add_mesh(tris, *trs)
         want_env = cfg["env"] if env is None else env
         if want_env:

@@ -182,6 +182,9 @@ typedef struct PtStats {
     float msCamera;
     uint32_t launchesIntersect;
     uint32_t launchesShade;
+    uint64_t shadeNodesVisited;  /* the shade stage's share of the three traversal     */
+    uint64_t shadeTrisTested;    /* counters above (shadow rays); the rest belongs to  */
+    uint64_t shadeMeshHits;      /* the intersect stage                                */
 } PtStats;
 
 /* Closest-hit record for the fixed-ray-set parity hook. */
@@ -199,7 +202,10 @@ enum PtOption {
     PT_OPT_USE_BVH = 2,          /* USE_BVH, src/pathtrace.cu:193 (default 1)       */
     PT_OPT_STAGE_TIMING = 3,     /* bracket every stage with HIP events (default 0) */
     PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
-    PT_OPT_USE_GRAPH = 5         /* replay the iteration from a hipGraph (default 0)*/
+    PT_OPT_USE_GRAPH = 5,        /* replay the iteration from a hipGraph (default 0)*/
+    PT_OPT_BATCH = 6             /* iterations that share one launch group in
+                                    pt_trace_range (default 16, at most 64); results
+                                    do not depend on it                              */
 };
 
 /* pathtraceInit (src/pathtrace.cu:428-576): uploads the scene, builds lights,
@@ -214,7 +220,9 @@ int pt_destroy(PtContext* ctx);
  * context's stream. */
 int pt_trace(PtContext* ctx, int iter);
 
-/* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end. */
+/* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end.  Up to
+ * PT_OPT_BATCH iterations run through the same kernel launches (each with its own
+ * queue, so results equal one pt_trace call per iteration, bit for bit). */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE

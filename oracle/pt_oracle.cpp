@@ -1471,7 +1471,7 @@ void oracle_trace(Oracle* o, int iter)
     int depth = 0, n = N;
     bool firstBounce = true;
     memset(o->stats.lastLive, 0, sizeof(o->stats.lastLive));
-    uint64_t cn = 0, ct = 0, ch = 0;
+    uint64_t cn = 0, ct = 0, ch = 0, sn = 0, stt = 0, sh = 0;
     while (true) {
         if (depth < PT_MAX_DEPTH) o->stats.lastLive[depth] = (uint32_t)n;
         o->stats.pathBounces += (uint64_t)n;
@@ -1499,11 +1499,11 @@ void oracle_trace(Oracle* o, int iter)
             o->isects.swap(o->isectsSorted);
         }
         /* shade :2829-2847 */
-#pragma omp parallel for schedule(dynamic, 256) reduction(+ : cn, ct, ch)
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : sn, stt, sh)
         for (int i = 0; i < n; i++) {
             Counters c;
             shadeSlot(*o, iter, depth, i, o->paths[i], o->isects[i], firstBounce, c);
-            cn += c.nodes; ct += c.tris; ch += c.meshHits;
+            sn += c.nodes; stt += c.tris; sh += c.meshHits;
         }
         firstBounce = false;
         /* gatherTerminatedPaths :2641-2653 */
@@ -1520,7 +1520,8 @@ void oracle_trace(Oracle* o, int iter)
     for (int i = 0; i < n; i++) o->image[o->paths[i].pixelIndex] += o->paths[i].color;
     o->stats.lastDepth = (uint32_t)depth;
     o->stats.iterations++;
-    o->stats.nodesVisited += cn; o->stats.trisTested += ct; o->stats.meshHits += ch;
+    o->stats.nodesVisited += cn + sn; o->stats.trisTested += ct + stt; o->stats.meshHits += ch + sh;
+    o->stats.shadeNodesVisited += sn; o->stats.shadeTrisTested += stt; o->stats.shadeMeshHits += sh;
 }
 
 void oracle_image(Oracle* o, float* rgb)

@@ -197,6 +197,31 @@ def test_material_sort_off_bit_exact(pt, scenes, orc, gpu_ok):
     assert not np.array_equal(tr.image(), tr2.image())
 
 
+def test_batched_iterations_bit_exact(pt, scenes, orc, gpu_ok):
+    """pt_trace_range runs several iterations through the same launches (one queue each); the image must
+    equal the one-iteration-at-a-time result bit for bit, for any batch size and any stride."""
+    sc = scenes.make_scene("cornell", res=(96, 64), depth=8)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    for it in range(2, 25, 2):
+        o.trace(it)
+    ref = o.image()
+    for batch in (1, 5, 8, 12):
+        tr = pt.Tracer(sc)
+        tr.set_option(pt.PT_OPT_BATCH, batch)
+        tr.trace_range(2, 25, 2)
+        assert _same_bits(tr.image(), ref), batch
+        s = tr.stats()
+        assert s.pathBounces == o.stats().pathBounces and s.iterations == 12
+        assert list(s.lastLive[:9]) == list(o.stats().lastLive[:9])
+    sc = scenes.make_scene("dragon", res=(80, 48), depth=8, grid=(40, 41), env_size=(64, 32), tex_size=16)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    for it in range(1, 8):
+        o.trace(it)
+    tr = pt.Tracer(sc)
+    tr.trace_range(1, 8)
+    assert _same_bits(tr.image(), o.image())
+
+
 def test_depth_one_and_tiny_images(pt, scenes, orc, gpu_ok):
     for res, depth in (((1, 1), 8), ((3, 2), 1), ((257, 1), 2), ((16, 16), 1)):
         sc = scenes.make_scene("cornell", res=res, depth=depth)
@@ -261,7 +286,9 @@ def test_sample_split_equals_single_render(pt, scenes, orc, gpu_ok):
     assert single.stats().pathBounces > 0
 
 
-def test_counters_match_oracle(pt, scenes, orc, gpu_ok):
+def test_counters(pt, scenes, orc, gpu_ok):
+    """Traversal counters: the same closest hits as the oracle (mesh-hit counts are traversal-independent);
+    the ordered 4-wide traversal must test fewer triangles than the reference's unordered binary walk."""
     sc = scenes.make_scene("dragon", res=(64, 64), depth=4, grid=(48, 49), env_size=(64, 32), tex_size=16)
     tr = pt.Tracer(sc)
     tr.set_option(pt.PT_OPT_COUNTERS, 1)
@@ -269,8 +296,9 @@ def test_counters_match_oracle(pt, scenes, orc, gpu_ok):
     tr.trace(1)
     o.trace(1)
     gs, os_ = tr.stats(), o.stats()
-    assert (gs.nodesVisited, gs.trisTested, gs.meshHits) == (os_.nodesVisited, os_.trisTested, os_.meshHits)
-    assert gs.nodesVisited > 0
+    assert gs.meshHits == os_.meshHits and gs.shadeMeshHits == os_.shadeMeshHits
+    assert 0 < gs.trisTested <= os_.trisTested
+    assert 0 < gs.nodesVisited < os_.nodesVisited
 
 
 def test_errors_are_reported(pt, scenes, gpu_ok):
