@@ -19,7 +19,7 @@ except ImportError:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi_pathtrace.so")
+LIB_PATH = os.environ.get("MI_PATHTRACE_LIB") or os.path.join(_HERE, "csrc", "libmi_pathtrace.so")
 
 PT_SPHERE, PT_CUBE, PT_GLTF_MESH = 0, 1, 2
 PT_DIFFUSE, PT_SPECULAR, PT_REFRACTIVE, PT_PBR, PT_EMITTING = 0, 1, 2, 3, 4

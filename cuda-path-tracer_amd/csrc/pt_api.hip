@@ -20,13 +20,15 @@ using namespace ptd;
 void pt_set_error(const char* fmt, ...);
 
 void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q);
-void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
+void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
+                   uint32_t* workCtr, void* dc);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
-void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
+void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
+               uint32_t* shadowFetchCtr, uint32_t* shadowCount, void* dc);
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
-void ptl_intersect_rays(hipStream_t s, const SceneView& S, const float* o, const float* d, int n, PtHit* out);
+void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out, uint32_t* fetchCtr);
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d);
 void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, float* out);
 
@@ -41,6 +43,10 @@ void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, floa
 
 constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
 constexpr int kMaxBatch = 64;
+/* device work counters, zeroed before every launch group: [section][bounce][batch row] with sections
+ * 0 = next slot of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length */
+constexpr int kWorkCtrSection = (PT_MAX_DEPTH + 1) * kMaxBatch;
+constexpr int kWorkCtrCount = 3 * kWorkCtrSection;
 
 enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_COUNT };
 
@@ -53,6 +59,8 @@ struct PtContext {
     PathState state{};
     Queues queues{};
     DevCounters* dc = nullptr;
+    uint32_t* workCtr = nullptr;
+    int bvhMeshGeoms = 0;               /* mesh geoms that own a BVH */
     PtCamera cam{};
     int traceDepth = 8;
     int numPixels = 0;
@@ -123,7 +131,8 @@ int allocBatchState(PtContext* c, int batch)
     int rc;
 #define BA(ptr, count, zero) if ((rc = batchAlloc(c, &(ptr), (count), (zero))) != PT_OK) return rc
     BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
-    BA(P.hitA, N * B, false); BA(P.hitB, N * B, false);
+    BA(P.hitA, N * B, false); BA(P.hitB, N * B, false); BA(P.hitTri, N * B, false);
+    BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.shQueue, N * B, false);
     BA(P.image, N * B * 3, true);
     BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);
     BA(Q.blockHist, (size_t)Q.numBuckets * Q.numBlocks * B, false);
@@ -491,6 +500,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
             G.triStart = (int)(allHot.size() / 3);
             G.triCount = pm.triangleCount;
             G.hasBvh = fm.hasBvh ? 1 : 0;
+            if (fm.hasBvh) c->bvhMeshGeoms++;
             /* leafOfOrig is indexed by triStart + original index; keep both arrays aligned */
             size_t ntriFlat = fm.hot.size() / 3;
             allNodes.insert(allNodes.end(), fm.nodes.begin(), fm.nodes.end());
@@ -555,6 +565,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     V.envWidth = envOn ? d->env.width : 0; V.envHeight = envOn ? d->env.height : 0; V.envEnabled = envOn ? 1 : 0; V.useBvh = 1;
     V.envTotalPower = totalPower;
     V.numBuckets = d->materialCount + 1;
+    V.numBvhMeshes = c->bvhMeshGeoms;
 
     /* ---- running sum, path state and queues */
     const size_t N = (size_t)c->numPixels;
@@ -567,6 +578,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
         batch = std::max(1, std::min(batch, kMaxBatch));
         TRY_RC(allocBatchState(c, batch));
     }
+    TRY_RC(devAlloc(c, &c->workCtr, (size_t)kWorkCtrCount));
     TRY_RC(devAlloc(c, &c->dc, 1));
     TRY_HIP(hipMemset(c->dc, 0, sizeof(DevCounters)));
     TRY_HIP(hipDeviceSynchronize());
@@ -582,12 +594,16 @@ static int traceBatch(PtContext* c, Batch bt)
     hipStream_t s = c->stream;
     SceneView V = c->view;
     V.useBvh = c->useBvh;
+    V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
     const bool count = c->counters != 0;
+    uint32_t* ctr = c->workCtr;
+    HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
     { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, bt, c->traceDepth, c->state, c->queues); }
     for (int b = 0; b < c->traceDepth; ++b) {
-        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, bt, b, c->sortOn, count, c->dc); }
+        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + (size_t)b * kMaxBatch, c->dc); }
         if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, bt, b, V.numBuckets); }
-        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, c->dc); }
+        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + kWorkCtrSection + (size_t)b * kMaxBatch,
+                                               ctr + 2 * kWorkCtrSection + (size_t)b * kMaxBatch, c->dc); }
         { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, bt, b, c->sortOn); }
     }
     ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc);
@@ -735,19 +751,25 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
     if (!c || n < 0 || (n > 0 && (!origins || !directions || !out))) { pt_set_error("pt_intersect_rays: bad argument"); return PT_EINVAL; }
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
+    /* the rays go through the production intersect stage in chunks of one image's worth of paths */
+    const int chunk = std::min(n, c->numPixels);
     float *dO = nullptr, *dD = nullptr; PtHit* dH = nullptr;
-    HIP_TRY(hipMalloc((void**)&dO, (size_t)n * 12));
-    hipError_t e1 = hipMalloc((void**)&dD, (size_t)n * 12);
-    hipError_t e2 = hipMalloc((void**)&dH, (size_t)n * sizeof(PtHit));
+    HIP_TRY(hipMalloc((void**)&dO, (size_t)chunk * 12));
+    hipError_t e1 = hipMalloc((void**)&dD, (size_t)chunk * 12);
+    hipError_t e2 = hipMalloc((void**)&dH, (size_t)chunk * sizeof(PtHit));
     int rc = PT_OK;
     if (e1 != hipSuccess || e2 != hipSuccess) { pt_set_error("pt_intersect_rays: out of device memory"); rc = PT_ENOMEM; }
-    if (rc == PT_OK) {
-        SceneView V = c->view;
-        V.useBvh = c->useBvh;
-        hipError_t e = hipMemcpyAsync(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dD, directions, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) { ptl_intersect_rays(c->stream, V, dO, dD, n, dH); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipMemcpyAsync(out, dH, (size_t)n * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
+    SceneView V = c->view;
+    V.useBvh = c->useBvh;
+    V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
+    uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch;     /* a slot no bounce of a trace uses */
+    for (int first = 0; rc == PT_OK && first < n; first += chunk) {
+        const int m = std::min(chunk, n - first);
+        hipError_t e = hipMemcpyAsync(dO, origins + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) { ptl_intersect_rays(c->stream, V, c->state, c->queues, dO, dD, m, dH, ctr); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(out + first, dH, (size_t)m * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); rc = PT_EHIP; }
     }

@@ -72,52 +72,208 @@ __global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int t
     st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
 }
 
-/* --------------------------------------------------------------- intersect */
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_intersect(SceneView S, PathState st, Queues q, int bounce, int sortOn, DevCounters* dc)
+/* --------------------------------------------------------------- intersect
+ * The closest hit of a ray is found in two kernels.
+ *
+ * k_trace (persistent) walks the BVH meshes.  Per-ray cost there is heavy-tailed (a ray that
+ * misses the mesh box takes one step, a grazing ray hundreds), so a wave that walks 64 fixed rays
+ * in lockstep idles most lanes.  Here every lane owns its traversal state and pulls the next
+ * queue slot from a device counter as soon as its ray is finished; finished lanes are refilled
+ * together once enough of the wave is idle, so set-up and write-back code runs with many lanes.
+ * The grid is sized to the machine (not to the ray count) and every wave leaves its loop when the
+ * counter has passed the item count.  The same kernel, in shadow mode, finishes the shadow rays the
+ * shade stage left open.
+ *
+ * k_prims (one thread per slot, coherent) folds boxes, spheres and linear-scan meshes into the
+ * mesh result, writes the final hit record and the sort bucket, and builds this workgroup's bucket
+ * histogram.
+ *
+ * Per geom the test is the reference's (computeIntersectionsBVH, src/pathtrace.cu:834-934); the
+ * closest of all geoms is order-independent once equal distances go to the lower geom index, which
+ * is what the reference's in-order strict '<' loop yields. */
+#ifndef PT_REFILL
+#define PT_REFILL 32
+#endif
+#ifndef PT_TRACE_MINWAVES
+#define PT_TRACE_MINWAVES 4
+#endif
+#ifndef PT_SHADE_MINWAVES
+#define PT_SHADE_MINWAVES 4
+#endif
+constexpr int kRefillThreshold = PT_REFILL;
+
+PT_DEV int nextBvhMesh(const SceneView& S, int from)
+{
+    for (int i = from; i < S.numGeoms; ++i)
+        if (isBvhMesh(S, S.geoms[i])) return i;
+    return -1;
+}
+
+enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1 };
+
+/* items: TRACE_CLOSEST -> queue slots [0, live[bounce]); TRACE_SHADOW -> shadow queue [0, *shadowCount) */
+template <int MODE, bool COUNT>
+__global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S, PathState st, Queues q, int bounce,
+                                                                     uint32_t* fetchCtr, const uint32_t* shadowCount, DevCounters* dc)
 {
     __shared__ int s_stack[kStackDepth * kBlock];
+    const int tid = threadIdx.x;
+    const int lane = laneId();
+    st = st.at(blockIdx.y);
+    q = q.at(blockIdx.y);
+    const uint32_t n = MODE == TRACE_CLOSEST ? q.live[bounce] : shadowCount[blockIdx.y];
+    if (n == 0) return;
+    uint32_t* ctr = fetchCtr + blockIdx.y;
+    int* stack = s_stack + tid;
+    int ovRef[kOverflowStack];
+    float ovT[kOverflowStack];
+    const unsigned long long lt = laneMaskLt();
+    const int firstMesh = nextBvhMesh(S, 0);          /* >= 0: the host launches this kernel only then */
+
+    bool trav = false, pending = false, exhausted = false;
+    int pix = -1, gi = 0;
+    Ray r; r.o = f3(0.0f); r.d = f3(0.0f);
+    Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0; best.uv.y = 0; best.geom = -1; best.tri = -1;
+    float shDist = 0.0f;        /* shadow mode: distance to the light sample */
+    int shLight = -1;           /* shadow mode: geom of the light, -1 for an environment ray */
+    bool blocked = false;
+    MeshTrav tv;
+    travInit(S.geoms[firstMesh], r, tv);
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+
+    while (true) {
+        unsigned long long idle = __ballot(!trav && !exhausted);
+        unsigned long long travMask = __ballot(trav);
+        if (travMask == 0 || __builtin_popcountll(idle) >= kRefillThreshold) {
+            if (pending) {
+                if (MODE == TRACE_CLOSEST) {
+                    st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
+                    st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
+                    st.hitTri[pix] = best.tri;
+                } else {
+                    /* settle the path colour, then the image add the shade stage held back */
+                    float4 c = st.col[pix];
+                    if (!blocked) {
+                        float4 v = st.shC[pix];
+                        c.x = v.x; c.y = v.y; c.z = v.z;
+                        st.col[pix] = c;
+                    }
+                    if (__float_as_int(c.w) == 0) {
+                        float* im = st.image + 3 * (size_t)pix;
+                        im[0] += c.x; im[1] += c.y; im[2] += c.z;
+                    }
+                }
+                pending = false;
+            }
+            if (idle) {
+                const int leader = __builtin_ctzll(idle);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(ctr, (uint32_t)__builtin_popcountll(idle));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (!trav && !exhausted) {
+                    const uint32_t sidx = base + (uint32_t)__builtin_popcountll(idle & lt);
+                    if (sidx < n) {
+                        if (MODE == TRACE_CLOSEST) {
+                            pix = bounce == 0 ? (int)sidx : q.q0[sidx];
+                            float4 o = st.rayO[pix], d = st.rayD[pix];
+                            r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+                            best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
+                        } else {
+                            pix = st.shQueue[sidx];
+                            float4 o = st.shO[pix], d = st.shD[pix];
+                            r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+                            shDist = o.w;
+                            shLight = __float_as_int(d.w);
+                            blocked = false;
+                        }
+                        gi = firstMesh;
+                        travInit(S.geoms[gi], r, tv);
+                        trav = true;
+                    } else {
+                        exhausted = true;
+                    }
+                }
+            }
+            if (__ballot(trav) == 0) {
+                if (__ballot(!exhausted) == 0) break;
+                continue;
+            }
+        }
+        if (trav) {
+            const DGeom& g = S.geoms[gi];
+            bool more = travStep<COUNT>(S.nodes + 8 * (size_t)g.nodeStart, S.triHot + 3 * (size_t)g.triStart, tv, stack, ovRef, ovT, cnt);
+            if (!more) {
+                F3 nn; F2 uv; int mat = 0, tri = -1;
+                float t = travFinish(S, g, r, tv, false, nn, uv, mat, tri);
+                if (COUNT && tv.best >= 0) cnt.meshHits++;
+                if (MODE == TRACE_CLOSEST) {
+                    if (closer(t, gi, best)) {
+                        t = travFinish(S, g, r, tv, true, nn, uv, mat, tri);
+                        best.t = t; best.n = nn; best.mat = mat; best.uv = uv; best.geom = gi; best.tri = tri;
+                    }
+                } else {
+                    blocked = shLight >= 0 ? blocksLight(t, shDist) : blocksEnv(t);
+                }
+                const int next = (MODE == TRACE_SHADOW && blocked) ? -1 : nextBvhMesh(S, gi + 1);
+                if (next >= 0) { gi = next; travInit(S.geoms[gi], r, tv); }
+                else { trav = false; pending = true; }
+            }
+        }
+    }
+    if (COUNT) flushCounters(cnt, dc, MODE);
+}
+
+/* fold the inline geoms into the mesh result; final hit record, sort bucket, bucket histogram */
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Queues q, int bounce, int sortOn, DevCounters* dc)
+{
     __shared__ int s_hist[kMaxBuckets];
     st = st.at(blockIdx.y);
     q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
+    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
     const int slot = blockIdx.x * kBlock + tid;
-    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;      /* whole workgroup beyond the live range */
-
-    const int nb = S.numBuckets;
+    const int numBuckets = S.numBuckets;
     if (sortOn) {
-        for (int i = tid; i < nb; i += kBlock) s_hist[i] = 0;
+        for (int i = tid; i < numBuckets; i += kBlock) s_hist[i] = 0;
         __syncthreads();
     }
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
     const bool active = (uint32_t)slot < n;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
     int key = 0;
     if (active) {
         const int pix = bounce == 0 ? slot : q.q0[slot];
         float4 o = st.rayO[pix], d = st.rayD[pix];
         Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
-        Hit h = closestHit<COUNT>(S, r, s_stack + tid, cnt);
-        st.hitA[pix] = make_float4(h.t, h.n.x, h.n.y, h.n.z);
-        st.hitB[pix] = make_float4(__int_as_float(h.mat), h.uv.x, h.uv.y, __int_as_float(h.geom));
+        Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
+        if (S.numBvhMeshes > 0) {
+            float4 ha = st.hitA[pix], hb = st.hitB[pix];
+            best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
+            best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
+            best.tri = st.hitTri[pix];
+        }
+        foldInlineGeoms<COUNT>(S, r, best, cnt);
+        st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
+        st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
+        st.hitTri[pix] = best.tri;
         /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */
-        key = (h.t > 0.0f) ? h.mat : (nb - 1);
+        key = (best.t > 0.0f) ? best.mat : (numBuckets - 1);
         if (sortOn) q.keys[slot] = key;
     }
     if (COUNT) flushCounters(cnt, dc, 0);
-    if (sortOn) {
-        /* wave-aggregated histogram: one LDS atomic per distinct bucket per wave */
-        unsigned long long todo = __ballot(active);
-        while (todo) {
-            int leader = __builtin_ctzll(todo);
-            int k = __shfl(key, leader);
-            unsigned long long m = __ballot(active && key == k);
-            if (laneId() == leader) atomicAdd(&s_hist[k], (int)__builtin_popcountll(m));
-            todo &= ~m;
-        }
-        __syncthreads();
-        for (int i = tid; i < nb; i += kBlock) q.blockHist[(size_t)i * q.numBlocks + blockIdx.x] = s_hist[i];
+    if (!sortOn) return;
+    /* wave-aggregated: one LDS atomic per distinct bucket per wave */
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        int leader = __builtin_ctzll(todo);
+        int k = __shfl(key, leader);
+        unsigned long long m = __ballot(active && key == k);
+        if (laneId() == leader) atomicAdd(&s_hist[k], (int)__builtin_popcountll(m));
+        todo &= ~m;
     }
+    __syncthreads();
+    for (int i = tid; i < numBuckets; i += kBlock) q.blockHist[(size_t)i * q.numBlocks + blockIdx.x] = s_hist[i];
 }
 
 /* block-wide exclusive scan helper for 1024 threads; returns the exclusive prefix of v and the
@@ -222,11 +378,15 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, i
     }
 }
 
-/* ------------------------------------------------------------------- shade */
+/* ------------------------------------------------------------------- shade
+ * One thread per sorted slot.  Shadow rays are tested against the inline geoms here; when BVH
+ * meshes exist and nothing inline blocks, the ray goes to the shadow queue with the path colour of
+ * the unblocked outcome, and the path itself continues with the blocked outcome until k_trace in
+ * shadow mode settles it (before the next stage reads the colour). */
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Queues q, Batch bt, int bounce, int sortOn, DevCounters* dc)
+__global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S, PathState st, Queues q, Batch bt, int bounce, int sortOn,
+                                                                     uint32_t* shadowCount, DevCounters* dc)
 {
-    __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ int s_alive[kBlock / 64];
     st = st.at(blockIdx.y);
     q = q.at(blockIdx.y);
@@ -239,8 +399,11 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Que
     int* queue = sortOn ? q.q1 : q.q0;
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
     bool alive = false;
+    ShadowReq sq;
+    sq.pending = false; sq.o = f3(0.0f); sq.d = f3(0.0f); sq.dist = 0.0f; sq.lightGeom = -1; sq.colorVisible = f3(0.0f);
+    int pix = 0;
     if (active) {
-        const int pix = (!sortOn && bounce == 0) ? slot : queue[slot];
+        pix = (!sortOn && bounce == 0) ? slot : queue[slot];
         float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
         float4 ha = st.hitA[pix], hb = st.hitB[pix];
         Path p;
@@ -248,12 +411,13 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Que
         p.remaining = __float_as_int(c.w);
         p.prevSpecular = __float_as_int(o.w) != 0;
         F2 uv; uv.x = hb.y; uv.y = hb.z;
-        shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0,
-                         s_stack + tid, cnt);
+        shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0, sq, cnt);
         alive = p.remaining > 0;
         if (alive) {
             st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
             st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, 0.0f);
+        }
+        if (alive || sq.pending) {
             st.col[pix] = make_float4(p.color.x, p.color.y, p.color.z, __int_as_float(p.remaining));
         } else if (p.remaining == 0) {
             /* gatherTerminatedPaths (src/pathtrace.cu:2641-2653): one path per pixel, so a plain add */
@@ -261,6 +425,22 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView S, PathState st, Que
             im[0] += p.color.x; im[1] += p.color.y; im[2] += p.color.z;
         }
         queue[slot] = alive ? pix : (-1 - pix);
+    }
+    /* shadow queue append: one atomic per wave */
+    {
+        unsigned long long pm = __ballot(sq.pending);
+        if (pm) {
+            const int leader = __builtin_ctzll(pm);
+            uint32_t base = 0;
+            if (laneId() == leader) base = atomicAdd(shadowCount + blockIdx.y, (uint32_t)__builtin_popcountll(pm));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (sq.pending) {
+                st.shQueue[base + (uint32_t)__builtin_popcountll(pm & laneMaskLt())] = pix;
+                st.shO[pix] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
+                st.shD[pix] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
+                st.shC[pix] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, 0.0f);
+            }
+        }
     }
     if (COUNT) flushCounters(cnt, dc, 1);
     unsigned long long m = __ballot(alive);
@@ -387,22 +567,6 @@ __global__ void __launch_bounds__(kBlock) k_display(const float* image, int n, i
     reinterpret_cast<uchar4*>(rgba)[i] = px;
 }
 
-/* parity hook: closest hit of arbitrary rays through the intersect stage's device code */
-__global__ void __launch_bounds__(kBlock) k_intersect_rays(SceneView S, const float* o, const float* d, int n, PtHit* out)
-{
-    __shared__ int s_stack[kStackDepth * kBlock];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    Ray r; r.o = f3(o + 3 * (size_t)i); r.d = f3(d + 3 * (size_t)i);
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
-    Hit h = closestHit<false>(S, r, s_stack + threadIdx.x, cnt);
-    PtHit ph;
-    ph.t = h.t; ph.geom = h.geom; ph.triangle = h.tri; ph.materialId = h.t > 0.0f ? h.mat : -1;
-    ph.normal[0] = h.n.x; ph.normal[1] = h.n.y; ph.normal[2] = h.n.z;
-    ph.uv[0] = h.uv.x; ph.uv[1] = h.uv.y;
-    out[i] = ph;
-}
-
 __global__ void __launch_bounds__(kBlock) k_export_rays(PathState st, int n, float* o, float* d)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -410,6 +574,28 @@ __global__ void __launch_bounds__(kBlock) k_export_rays(PathState st, int n, flo
     float4 a = st.rayO[i], b = st.rayD[i];
     o[3 * (size_t)i] = a.x; o[3 * (size_t)i + 1] = a.y; o[3 * (size_t)i + 2] = a.z;
     d[3 * (size_t)i] = b.x; d[3 * (size_t)i + 1] = b.y; d[3 * (size_t)i + 2] = b.z;
+}
+
+/* stage-level hook: caller rays into row 0 of the path state, final hit records out */
+__global__ void __launch_bounds__(kBlock) k_import_rays(PathState st, Queues q, int n, const float* o, const float* d)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) q.live[0] = (uint32_t)n;
+    if (i >= n) return;
+    st.rayO[i] = make_float4(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2], 0.0f);
+    st.rayD[i] = make_float4(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2], 0.0f);
+}
+__global__ void __launch_bounds__(kBlock) k_export_hits(PathState st, int n, PtHit* out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 ha = st.hitA[i], hb = st.hitB[i];
+    PtHit ph;
+    ph.t = ha.x; ph.geom = __float_as_int(hb.w); ph.triangle = st.hitTri[i];
+    ph.materialId = ha.x > 0.0f ? __float_as_int(hb.x) : -1;
+    ph.normal[0] = ha.y; ph.normal[1] = ha.z; ph.normal[2] = ha.w;
+    ph.uv[0] = hb.y; ph.uv[1] = hb.z;
+    out[i] = ph;
 }
 
 __global__ void __launch_bounds__(kBlock) k_math(int fn, const float* a, const float* b, int n, float* out)
@@ -446,20 +632,38 @@ void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathSta
 {
     hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1]), bt.count), dim3(kBlock), 0, s, cam, bt, depth, st, q);
 }
-void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc)
+static inline int persistentGridX(int batch)
 {
-    if (count) hipLaunchKernelGGL(k_intersect<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_intersect<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    /* 256 CUs x 4 workgroups of 4 waves = 16 waves per CU in flight; split over the batch rows */
+    int x = (1024 + batch - 1) / batch;
+    return x < 1 ? 1 : x;
+}
+void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
+                   uint32_t* fetchCtr, void* dc)
+{
+    if (S.numBvhMeshes > 0) {
+        dim3 grid(persistentGridX(bt.count), bt.count);
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)nullptr, (DevCounters*)dc);
+        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)nullptr, (DevCounters*)dc);
+    }
+    if (count) hipLaunchKernelGGL(k_prims<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_prims<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
 }
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
 {
     hipLaunchKernelGGL(k_sort_scan, dim3(1, bt.count), dim3(1024), 0, s, q, bounce, numBuckets);
     hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, numBuckets);
 }
-void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc)
+void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
+               uint32_t* shadowFetchCtr, uint32_t* shadowCount, void* dc)
 {
-    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, (DevCounters*)dc);
+    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, (DevCounters*)dc);
+    if (S.numBvhMeshes > 0) {
+        dim3 grid(persistentGridX(bt.count), bt.count);
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, shadowFetchCtr, (const uint32_t*)shadowCount, (DevCounters*)dc);
+        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, shadowFetchCtr, (const uint32_t*)shadowCount, (DevCounters*)dc);
+    }
 }
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
 {
@@ -478,9 +682,13 @@ void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rg
 {
     hipLaunchKernelGGL(k_display, dim3(gridFor(n)), dim3(kBlock), 0, s, image, n, iter, rgba);
 }
-void ptl_intersect_rays(hipStream_t s, const SceneView& S, const float* o, const float* d, int n, PtHit* out)
+/* n <= st.numPixels rays through the production intersect stage (row 0 of the path state) */
+void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out, uint32_t* fetchCtr)
 {
-    hipLaunchKernelGGL(k_intersect_rays, dim3(gridFor(n)), dim3(kBlock), 0, s, S, o, d, n, out);
+    hipLaunchKernelGGL(k_import_rays, dim3(gridFor(n)), dim3(kBlock), 0, s, st, q, n, o, d);
+    Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
+    ptl_intersect(s, S, st, q, bt, 0, 0, false, fetchCtr, nullptr);
+    hipLaunchKernelGGL(k_export_hits, dim3(gridFor(n)), dim3(kBlock), 0, s, st, n, out);
 }
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d)
 {

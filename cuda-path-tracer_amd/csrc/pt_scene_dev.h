@@ -64,6 +64,7 @@ struct SceneView {
     int envWidth, envHeight, envEnabled, useBvh;
     float envTotalPower;
     int numBuckets;                 /* numMaterials + 1 */
+    int numBvhMeshes;               /* mesh geoms traversed through their BVH (0 when BVH use is off) */
 };
 
 /* Several iterations ("a batch") run through the same launches, one grid row (blockIdx.y) each.
@@ -76,12 +77,20 @@ struct PathState {
     float4* hitA;
     float4* hitB;
     float* image;                   /* W*H*3: this iteration's contribution inside the kernels */
+    int* hitTri;                    /* mesh-local triangle of the hit (parity hook) */
+    /* shadow rays whose mesh part is still to be traced: (origin, max distance) (direction, light geom
+       or -1 for the environment) (path colour if the ray turns out unoccluded) */
+    float4* shO;
+    float4* shD;
+    float4* shC;
+    int* shQueue;                   /* pixels with a pending shadow ray, in arrival order */
     size_t numPixels;
     PT_DEV PathState at(int k) const
     {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
         r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.image += 3 * off;
+        r.hitTri += off; r.shO += off; r.shD += off; r.shC += off; r.shQueue += off;
         return r;
     }
 };
@@ -226,109 +235,118 @@ PT_DEV float hitTriangle(const float4* hot, F3 lo, F3 ld, F3& bary)
  * stack: this lane's column of a [kStackDepth][kBlock] LDS array (refs in rows 0..kLdsStack-1,
  * entry distances in the rows above); deeper entries spill to private memory.
  * Returns world distance or -1; attributes are fetched only when wantAttr. */
-template <bool COUNT>
-PT_DEV float hitMesh(const SceneView& S, const DGeom& g, const Ray& r, int* stack, bool wantAttr,
-                     F3& N, F2& uv, int& mat, int& triOrig, TravCounters& cnt)
-{
-    F3 lo = mulMV(g.I, r.o, 1.0f);
-    F3 ld = normalize(mulMV(g.I, r.d, 0.0f));
-    float closestT = 3.402823466e+38f;
-    int best = -1;
-    int bestRank = 0x7fffffff;
-    F3 bestBary = f3(0.0f);
-    const float4* hot = S.triHot + 3 * (size_t)g.triStart;
+struct MeshTrav {
+    F3 lo, ld, invDir;          /* ray in the mesh's object space */
+    float closestT;
+    int best, bestRank;
+    F3 bary;
+    int sp, ref;
+};
 
-    if (S.useBvh && g.hasBvh) {
-        const F3 invDir = 1.0f / ld;
-        const float4* nodes = S.nodes + 8 * (size_t)g.nodeStart;
-        const float INF = __builtin_inff();
-        int ovRef[kOverflowStack];
-        float ovT[kOverflowStack];
-        int sp = 0;
-        int ref = 0;
-        while (true) {
-            if (ref >= 0) {
-                const float4* q = nodes + 8 * (size_t)ref;
-                float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-                float4 rf = q[6];
-                if (COUNT) cnt.nodes++;
-                float tk[4];
-                int rk[4];
+PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
+{
+    tv.lo = mulMV(g.I, r.o, 1.0f);
+    tv.ld = normalize(mulMV(g.I, r.d, 0.0f));
+    tv.invDir = 1.0f / tv.ld;
+    tv.closestT = 3.402823466e+38f;
+    tv.best = -1;
+    tv.bestRank = 0x7fffffff;
+    tv.bary = f3(0.0f);
+    tv.sp = 0;
+    tv.ref = 0;
+}
+
+/* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
+ * closer-or-equal hit.  Returns false when the stack has run dry. */
+template <bool COUNT>
+PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt)
+{
+    const float INF = __builtin_inff();
+    const int ref = tv.ref;
+    if (ref >= 0) {
+        const float4* q = nodes + 8 * (size_t)ref;
+        float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+        float4 rf = q[6];
+        if (COUNT) cnt.nodes++;
+        float tk[4];
+        int rk[4];
+        const F3 lo = tv.lo, invDir = tv.invDir;
+        const float closestT = tv.closestT;
 #define PT_CHILD(k, C)                                                                              \
-                {                                                                                    \
-                    float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;           \
-                    float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;           \
-                    float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;           \
-                    float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1)); \
-                    float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1)); \
-                    int cr = __float_as_int(rf.C);                                                   \
-                    bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT); \
-                    tk[k] = in ? tMin : INF;                                                         \
-                    rk[k] = cr;                                                                      \
-                }
-                PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
+        {                                                                                            \
+            float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;                   \
+            float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;                   \
+            float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;                   \
+            float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));        \
+            float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));        \
+            int cr = __float_as_int(rf.C);                                                           \
+            bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);     \
+            tk[k] = in ? tMin : INF;                                                                 \
+            rk[k] = cr;                                                                              \
+        }
+        PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
 #undef PT_CHILD
-                /* nearest first: 5-exchange network on (distance, ref) */
+        /* nearest first: 5-exchange network on (distance, ref) */
 #define PT_CSWAP(i, j) { bool sw = tk[j] < tk[i]; float tt_ = sw ? tk[j] : tk[i]; float tu_ = sw ? tk[i] : tk[j]; \
                          int ra_ = sw ? rk[j] : rk[i]; int rb_ = sw ? rk[i] : rk[j]; tk[i] = tt_; tk[j] = tu_; rk[i] = ra_; rk[j] = rb_; }
-                PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+        PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
+        int sp = tv.sp;
 #define PT_PUSH(k)                                                                                   \
-                if (tk[k] < INF) {                                                                   \
-                    if (sp < kLdsStack) { stack[sp * kBlock] = rk[k]; stack[(kLdsStack + sp) * kBlock] = __float_as_int(tk[k]); sp++; } \
-                    else if (sp < kLdsStack + kOverflowStack) { ovRef[sp - kLdsStack] = rk[k]; ovT[sp - kLdsStack] = tk[k]; sp++; }     \
-                }
-                PT_PUSH(3) PT_PUSH(2) PT_PUSH(1)
-#undef PT_PUSH
-                if (tk[0] < INF) { ref = rk[0]; continue; }
-            } else {
-                const unsigned x = ~(unsigned)ref;
-                const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
-                for (int i = 0; i < count; ++i) {
-                    F3 bary;
-                    const float4* tp = hot + 3 * (size_t)(first + i);
-                    float tt = hitTriangle(tp, lo, ld, bary);
-                    if (COUNT) cnt.tris++;
-                    if (tt > 0.0f && !(tt > closestT)) {
-                        int rank = __float_as_int(tp[2].z);
-                        if (tt < closestT || rank < bestRank) { closestT = tt; bestBary = bary; best = first + i; bestRank = rank; }
-                    }
-                }
-            }
-            /* pop the next entry that can still hold a closer (or equal) hit */
-            bool found = false;
-            while (sp > 0) {
-                sp--;
-                float t;
-                if (sp < kLdsStack) { ref = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]); }
-                else { ref = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack]; }
-                if (!(t > closestT)) { found = true; break; }
-            }
-            if (!found) break;
+        if (tk[k] < INF) {                                                                           \
+            if (sp < kLdsStack) { stack[sp * kBlock] = rk[k]; stack[(kLdsStack + sp) * kBlock] = __float_as_int(tk[k]); sp++; } \
+            else if (sp < kLdsStack + kOverflowStack) { ovRef[sp - kLdsStack] = rk[k]; ovT[sp - kLdsStack] = tk[k]; sp++; }     \
         }
+        PT_PUSH(3) PT_PUSH(2) PT_PUSH(1)
+#undef PT_PUSH
+        tv.sp = sp;
+        if (tk[0] < INF) { tv.ref = rk[0]; return true; }
     } else {
-        /* linear scan in ORIGINAL triangle order (meshIntersectionTest, src/intersections.cu:168-245) */
-        for (int i = 0; i < g.triCount; ++i) {
-            int leafPos = S.leafOfOrig[g.triStart + i];
+        const unsigned x = ~(unsigned)ref;
+        const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
+        for (int i = 0; i < count; ++i) {
             F3 bary;
-            float tt = hitTriangle(hot + 3 * (size_t)leafPos, lo, ld, bary);
+            const float4* tp = hot + 3 * (size_t)(first + i);
+            float tt = hitTriangle(tp, tv.lo, tv.ld, bary);
             if (COUNT) cnt.tris++;
-            if (tt > 0.0f && tt < closestT) { closestT = tt; bestBary = bary; best = leafPos; }
+            if (tt > 0.0f && !(tt > tv.closestT)) {
+                int rank = __float_as_int(tp[2].z);
+                if (tt < tv.closestT || rank < tv.bestRank) { tv.closestT = tt; tv.bary = bary; tv.best = first + i; tv.bestRank = rank; }
+            }
         }
     }
-    if (best < 0) return -1.0f;
-    if (COUNT) cnt.meshHits++;
-    F3 localP = lo + ld * closestT;
+    /* pop the next entry that can still hold a closer (or equal) hit */
+    int sp = tv.sp;
+    while (sp > 0) {
+        sp--;
+        float t;
+        int r2;
+        if (sp < kLdsStack) { r2 = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]); }
+        else { r2 = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack]; }
+        if (!(t > tv.closestT)) { tv.sp = sp; tv.ref = r2; return true; }
+    }
+    tv.sp = 0;
+    return false;
+}
+
+/* hit epilogue (src/intersections.cu:388-419): world distance, and when wantAttr the interpolated
+ * normal / uv / material of the best triangle */
+PT_DEV float travFinish(const SceneView& S, const DGeom& g, const Ray& r, const MeshTrav& tv, bool wantAttr,
+                        F3& N, F2& uv, int& mat, int& triOrig)
+{
+    if (tv.best < 0) return -1.0f;
+    const float4* hot = S.triHot + 3 * (size_t)g.triStart;
+    F3 localP = tv.lo + tv.ld * tv.closestT;
     F3 P = mulMV(g.T, localP, 1.0f);
     if (wantAttr) {
-        const float4* cold = S.triCold + 4 * (size_t)(g.triStart + best);
+        const float4* cold = S.triCold + 4 * (size_t)(g.triStart + tv.best);
         float4 c0 = cold[0], c1 = cold[1], c2 = cold[2], c3 = cold[3];
         F3 n0 = f3(c0.x, c0.y, c0.z), n1 = f3(c0.w, c1.x, c1.y), n2 = f3(c1.z, c1.w, c2.x);
-        F3 ln = normalize(bestBary.x * n0 + bestBary.y * n1 + bestBary.z * n2);
-        uv.x = (bestBary.x * c2.y + bestBary.y * c2.w) + bestBary.z * c3.y;
-        uv.y = (bestBary.x * c2.z + bestBary.y * c3.x) + bestBary.z * c3.z;
+        F3 ln = normalize(tv.bary.x * n0 + tv.bary.y * n1 + tv.bary.z * n2);
+        uv.x = (tv.bary.x * c2.y + tv.bary.y * c2.w) + tv.bary.z * c3.y;
+        uv.y = (tv.bary.x * c2.z + tv.bary.y * c3.x) + tv.bary.z * c3.z;
         mat = __float_as_int(c3.w);
-        triOrig = __float_as_int(hot[3 * (size_t)best + 2].y);
+        triOrig = __float_as_int(hot[3 * (size_t)tv.best + 2].y);
         N = normalize(mulMV(g.IT, ln, 0.0f));
         bool outside = dot(r.d, N) < 0.0f;
         if (!outside) N = -N;
@@ -336,41 +354,69 @@ PT_DEV float hitMesh(const SceneView& S, const DGeom& g, const Ray& r, int* stac
     return length(r.o - P);
 }
 
-/* closest hit over every geom, in geom order, strict '<' (src/pathtrace.cu:868-919) */
+/* linear scan in ORIGINAL triangle order (meshIntersectionTest, src/intersections.cu:168-245), for
+ * meshes that are not traced through their BVH */
 template <bool COUNT>
-PT_DEV Hit closestHit(const SceneView& S, const Ray& r, int* stack, TravCounters& cnt)
+PT_DEV float hitMeshLinear(const SceneView& S, const DGeom& g, const Ray& r, bool wantAttr,
+                           F3& N, F2& uv, int& mat, int& triOrig, TravCounters& cnt)
 {
-    Hit h;
-    h.t = -1.0f; h.n = f3(0.0f); h.mat = 0; h.uv.x = 0.0f; h.uv.y = 0.0f; h.geom = -1; h.tri = -1;
-    float tMinAll = 3.402823466e+38f;
+    MeshTrav tv;
+    travInit(g, r, tv);
+    const float4* hot = S.triHot + 3 * (size_t)g.triStart;
+    for (int i = 0; i < g.triCount; ++i) {
+        int leafPos = S.leafOfOrig[g.triStart + i];
+        F3 bary;
+        float tt = hitTriangle(hot + 3 * (size_t)leafPos, tv.lo, tv.ld, bary);
+        if (COUNT) cnt.tris++;
+        if (tt > 0.0f && tt < tv.closestT) { tv.closestT = tt; tv.bary = bary; tv.best = leafPos; }
+    }
+    if (COUNT && tv.best >= 0) cnt.meshHits++;
+    return travFinish(S, g, r, tv, wantAttr, N, uv, mat, triOrig);
+}
+
+/* true when geom i is traced by the persistent BVH kernel rather than inline */
+PT_DEV bool isBvhMesh(const SceneView& S, const DGeom& g) { return g.type == PT_GLTF_MESH && S.useBvh && g.hasBvh; }
+
+/* The closest hit over all geoms is the reference's in-order loop with a strict '<'
+ * (src/pathtrace.cu:868-919): the smallest distance wins and equal distances go to the lower geom
+ * index.  Written as that rule, candidates can be folded in any order. */
+PT_DEV bool closer(float t, int geom, const Hit& best)
+{
+    return t > 0.0f && (best.geom < 0 || t < best.t || (t == best.t && geom < best.geom));
+}
+
+/* fold every geom that is not a BVH mesh (boxes, spheres, meshes in linear-scan mode) into best */
+template <bool COUNT>
+PT_DEV void foldInlineGeoms(const SceneView& S, const Ray& r, Hit& best, TravCounters& cnt)
+{
     for (int i = 0; i < S.numGeoms; ++i) {
         const DGeom& g = S.geoms[i];
+        if (isBvhMesh(S, g)) continue;
         float t = -1.0f;
         F3 n = f3(0.0f);
         F2 uv; uv.x = 0.5f; uv.y = 0.5f;
         int mat = g.materialid, tri = -1;
         if (g.type == PT_CUBE) t = hitBox(g, r, n);
         else if (g.type == PT_SPHERE) t = hitSphere(g, r, n);
-        else if (g.type == PT_GLTF_MESH) t = hitMesh<COUNT>(S, g, r, stack, true, n, uv, mat, tri, cnt);
-        if (t > 0.0f && tMinAll > t) {
-            tMinAll = t;
-            h.t = t; h.n = n; h.mat = mat; h.uv = uv; h.geom = i; h.tri = tri;
-        }
+        else if (g.type == PT_GLTF_MESH) t = hitMeshLinear<COUNT>(S, g, r, true, n, uv, mat, tri, cnt);
+        if (closer(t, i, best)) { best.t = t; best.n = n; best.mat = mat; best.uv = uv; best.geom = i; best.tri = tri; }
     }
-    return h;
 }
 
-/* distance of the closest hit on one geom, for shadow rays */
+/* distance of the closest hit on one inline geom, for shadow rays */
 template <bool COUNT>
-PT_DEV float occluderDistance(const SceneView& S, int gi, const Ray& r, int* stack, TravCounters& cnt)
+PT_DEV float inlineOccluderDistance(const SceneView& S, const DGeom& g, const Ray& r, TravCounters& cnt)
 {
-    const DGeom& g = S.geoms[gi];
     F3 n; F2 uv; int m, tri;
     if (g.type == PT_SPHERE) return hitSphere(g, r, n);
     if (g.type == PT_CUBE) return hitBox(g, r, n);
-    if (g.type == PT_GLTF_MESH) return hitMesh<COUNT>(S, g, r, stack, false, n, uv, m, tri, cnt);
+    if (g.type == PT_GLTF_MESH) return hitMeshLinear<COUNT>(S, g, r, false, n, uv, m, tri, cnt);
     return -1.0f;
 }
+
+/* occlusion rules of the two shadow tests, per geom (src/pathtrace.cu:2222 and :2293) */
+PT_DEV bool blocksLight(float t, float dist) { return t > 0.001f && t < dist - 0.001f; }
+PT_DEV bool blocksEnv(float t) { return !(t < 0.001f); }
 
 /* ---------------------------------------------------------------- sampling */
 
@@ -545,30 +591,40 @@ PT_DEV float envPdf(const SceneView& S, F3 dir)
     return nanMax(pdf, 1e-6f);
 }
 
-/* shadow ray towards a sampled light point: blocked by the closest hit of any other geom
- * lying strictly between the two ends (src/pathtrace.cu:2171-2226) */
+/* A shadow ray is blocked when ANY geom blocks it (the reference's loops stop at the first blocker,
+ * src/pathtrace.cu:2174-2226 and :2271-2294), so the geoms can be tested in any order and in two places:
+ * boxes, spheres and linear-scan meshes right here in the shader, BVH meshes later in the traversal
+ * kernel.  These return true when no inline geom blocks the ray. */
 template <bool COUNT>
-PT_DEV bool lightVisible(const SceneView& S, const Ray& sh, int lightGeom, float dist, int* stack, TravCounters& cnt)
+PT_DEV bool lightVisibleInline(const SceneView& S, const Ray& sh, int lightGeom, float dist, TravCounters& cnt)
 {
     for (int gi = 0; gi < S.numGeoms; ++gi) {
         if (gi == lightGeom) continue;
-        float t = occluderDistance<COUNT>(S, gi, sh, stack, cnt);
-        if (t > 0.001f && t < dist - 0.001f) return false;
+        const DGeom& g = S.geoms[gi];
+        if (isBvhMesh(S, g)) continue;
+        if (blocksLight(inlineOccluderDistance<COUNT>(S, g, sh, cnt), dist)) return false;
     }
     return true;
 }
-/* shadow ray towards the environment: any geom whose closest hit is at t >= 0.001 blocks
- * (src/pathtrace.cu:2270-2294) */
 template <bool COUNT>
-PT_DEV bool envVisible(const SceneView& S, const Ray& sh, int* stack, TravCounters& cnt)
+PT_DEV bool envVisibleInline(const SceneView& S, const Ray& sh, TravCounters& cnt)
 {
-    bool visible = true;
-    for (int i = 0; i < S.numGeoms && visible; ++i) {
-        float t = occluderDistance<COUNT>(S, i, sh, stack, cnt);
-        visible = (t < 0.001f);
+    for (int i = 0; i < S.numGeoms; ++i) {
+        const DGeom& g = S.geoms[i];
+        if (isBvhMesh(S, g)) continue;
+        if (blocksEnv(inlineOccluderDistance<COUNT>(S, g, sh, cnt))) return false;
     }
-    return visible;
+    return true;
 }
+
+/* a shadow ray whose BVH-mesh part is still open when the shader returns */
+struct ShadowReq {
+    bool pending;
+    F3 o, d;
+    float dist;
+    int lightGeom;      /* -1: environment ray */
+    F3 colorVisible;    /* path colour if nothing blocks; the path itself carries the blocked outcome */
+};
 
 /* ----------------------------------------------------------------- shaders */
 
@@ -581,7 +637,7 @@ struct Path {
 /* Lambert + one-sample direct light chosen among {light, BRDF, environment}
  * (src/pathtrace.cu:2101-2327) */
 template <bool COUNT>
-PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 materialColor, Lcg& rng, int* stack, TravCounters& cnt)
+PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 materialColor, Lcg& rng, ShadowReq& sq, TravCounters& cnt)
 {
     const int nl = S.numLights;
     const bool env = S.envEnabled != 0;
@@ -609,7 +665,8 @@ PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 mat
             float NdotL = dot(normal, wi);
             if (NdotL > 0.0f) {
                 Ray sh; sh.o = P + normal * 0.001f; sh.d = wi;
-                if (lightVisible<COUNT>(S, sh, L.geomIdx, dist, stack, cnt)) {
+                if (lightVisibleInline<COUNT>(S, sh, L.geomIdx, dist, cnt)) {
+                    if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = dist; sq.lightGeom = L.geomIdx; }
                     F3 ln = normalize(lp - f3(lg.translation));
                     float NdotLl = nanMax(0.0f, dot(-wi, ln));
                     float pdfLight = 1.0f / (nanMax(L.area, 0.01f) * nl);
@@ -631,7 +688,8 @@ PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 mat
         float NdotL = dot(normal, ed);
         if (NdotL > 0.0f) {
             Ray sh; sh.o = P + normal * 0.001f; sh.d = ed;
-            if (envVisible<COUNT>(S, sh, stack, cnt)) {
+            if (envVisibleInline<COUNT>(S, sh, cnt)) {
+                if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = 0.0f; sq.lightGeom = -1; }
                 float pdfBRDF = NdotL / kPI;
                 float sum = ep + pdfBRDF;
                 float weight = ep / nanMax(sum, MIN_PDF);
@@ -643,6 +701,10 @@ PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 mat
     }
     F3 dir = sampleHemisphere(normal, rng);
     total = vclamp(total, f3(0.0f), f3(MAX_CONTRIBUTION));
+    if (sq.pending) {       /* both outcomes of the open shadow ray; the blocked one adds the same clamped zero */
+        sq.colorVisible = p.color * (materialColor + total);
+        total = vclamp(f3(0.0f), f3(0.0f), f3(MAX_CONTRIBUTION));
+    }
     p.color = p.color * (materialColor + total);
     p.o = P + normal * 0.001f;
     p.d = dir;
@@ -818,7 +880,7 @@ PT_DEV bool shadeSubsurface(Path& p, F3 P, F3 normal, const PtMaterial& m, F3 ma
  * direct light with the reference's weights, GGX / cosine lobe pick (src/pathtrace.cu:1708-2099) */
 template <bool COUNT>
 PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMaterial& m, float roughIn, float metallic,
-                     F3 albedo, float texAlpha, Lcg& rng, int* stack, TravCounters& cnt)
+                     F3 albedo, float texAlpha, Lcg& rng, ShadowReq& sq, TravCounters& cnt)
 {
     const int nl = S.numLights;
     const bool env = S.envEnabled != 0;
@@ -883,7 +945,8 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
             float NdotL = dot(normal, wi);
             if (NdotL > 0.0f) {
                 Ray sh; sh.o = P + normal * 0.001f; sh.d = wi;
-                if (lightVisible<COUNT>(S, sh, L.geomIdx, dist, stack, cnt)) {
+                if (lightVisibleInline<COUNT>(S, sh, L.geomIdx, dist, cnt)) {
+                    if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = dist; sq.lightGeom = L.geomIdx; }
                     float D, NdotH, VdotH;
                     F3 brdf = pbrBrdf(normal, wo, wi, NdotL, rough, metallic, albedo, F0, D, NdotH, VdotH);
                     F3 ln = normalize(lp - f3(lg.translation));
@@ -906,7 +969,8 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
         float NdotL = dot(normal, ed);
         if (NdotL > 0.0f) {
             Ray sh; sh.o = P + normal * 0.001f; sh.d = ed;
-            if (envVisible<COUNT>(S, sh, stack, cnt)) {
+            if (envVisibleInline<COUNT>(S, sh, cnt)) {
+                if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = 0.0f; sq.lightGeom = -1; }
                 float D, NdotH, VdotH;
                 F3 brdf = pbrBrdf(normal, wo, ed, NdotL, rough, metallic, albedo, F0, D, NdotH, VdotH);
                 float pdfBRDF = (NdotL / kPI) * (1.0f - metallic) + (D * NdotH / (4.0f * VdotH)) * metallic;
@@ -918,6 +982,9 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
         }
     }
     direct = vclamp(direct, f3(0.0f), f3(MAX_CONTRIBUTION));
+    F3 directVisible = direct;
+    if (sq.pending) direct = vclamp(f3(0.0f), f3(0.0f), f3(MAX_CONTRIBUTION));
+    sq.colorVisible = f3(0.0f);
 
     float specProb = 0.5f + 0.5f * metallic;
     if (rng.u01() < specProb) {
@@ -927,6 +994,7 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
             float VdotH = nanMax(0.0f, dot(wo, h));
             F3 F = schlick(VdotH, F0);
             F3 sc = mix(f3(1.0f), albedo, metallic);
+            if (sq.pending) sq.colorVisible = p.color * ((sc * F / specProb) + directVisible);
             p.color = p.color * ((sc * F / specProb) + direct);
             p.o = P + normal * 0.001f;
             p.d = wi;
@@ -939,6 +1007,7 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
         if (metallic < 1.0f) {
             F3 wi = sampleHemisphere(normal, rng);
             F3 dc = albedo * (1.0f - metallic);
+            if (sq.pending) sq.colorVisible = p.color * ((dc / (1.0f - specProb)) + directVisible);
             p.color = p.color * ((dc / (1.0f - specProb)) + direct);
             p.o = P + normal * 0.001f;
             p.d = wi;
@@ -955,7 +1024,7 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
  * dispatch, miss / environment (shadeMaterialMIS, src/pathtrace.cu:2455-2626) */
 template <bool COUNT>
 PT_DEV void shadeSlot(const SceneView& S, int iter, int bounceOneBased, int slot, Path& p, float t, F3 normal, int matId, F2 uv,
-                      bool firstBounce, int* stack, TravCounters& cnt)
+                      bool firstBounce, ShadowReq& sq, TravCounters& cnt)
 {
     if (p.remaining <= 0) return;
     Lcg rng;
@@ -1004,7 +1073,7 @@ PT_DEV void shadeSlot(const SceneView& S, int iter, int bounceOneBased, int slot
         switch (m.type) {
         case PT_DIFFUSE:
             p.prevSpecular = false;
-            shadeDiffuse<COUNT>(S, p, t, normal, mc, rng, stack, cnt);
+            shadeDiffuse<COUNT>(S, p, t, normal, mc, rng, sq, cnt);
             break;
         case PT_SPECULAR:
             p.prevSpecular = true;
@@ -1016,7 +1085,7 @@ PT_DEV void shadeSlot(const SceneView& S, int iter, int bounceOneBased, int slot
             break;
         case PT_PBR:
             p.prevSpecular = (rough < 0.1f && metallic > 0.5f);
-            shadePbr<COUNT>(S, p, t, normal, m, rough, metallic, mc, alpha, rng, stack, cnt);
+            shadePbr<COUNT>(S, p, t, normal, m, rough, metallic, mc, alpha, rng, sq, cnt);
             break;
         default:
             p.prevSpecular = false;
