@@ -130,23 +130,45 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     const unsigned long long lt = laneMaskLt();
     const int firstMesh = nextBvhMesh(S, 0);          /* >= 0: the host launches this kernel only then */
 
-    bool trav = false, pending = false, exhausted = false;
+    /* lane states: trav = walking mesh gi; done = that walk has ended and its epilogue is due;
+     * neither = wants a new item; exhausted = the counter has run past the last item */
+    bool trav = false, done = false, exhausted = false;
     int pix = -1, gi = 0;
     Ray r; r.o = f3(0.0f); r.d = f3(0.0f);
     Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0; best.uv.y = 0; best.geom = -1; best.tri = -1;
     float shDist = 0.0f;        /* shadow mode: distance to the light sample */
     int shLight = -1;           /* shadow mode: geom of the light, -1 for an environment ray */
-    bool blocked = false;
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
 
     while (true) {
-        unsigned long long idle = __ballot(!trav && !exhausted);
-        unsigned long long travMask = __ballot(trav);
-        if (travMask == 0 || __builtin_popcountll(idle) >= kRefillThreshold) {
-            if (pending) {
+        const unsigned long long idle = __ballot(!trav && !exhausted);
+        if (__ballot(trav) == 0 || __builtin_popcountll(idle) >= kRefillThreshold) {
+            /* epilogues and refills run together for all idle lanes */
+            bool fetch = !trav && !exhausted;
+            if (done) {
+                const DGeom& g = S.geoms[gi];
+                F3 nn; F2 uv; int mat = 0, tri = -1;
+                float t = travFinish(S, g, r, tv, false, nn, uv, mat, tri);
+                if (COUNT && tv.best >= 0) cnt.meshHits++;
+                bool blocked = false;
                 if (MODE == TRACE_CLOSEST) {
+                    if (closer(t, gi, best)) {
+                        t = travFinish(S, g, r, tv, true, nn, uv, mat, tri);
+                        best.t = t; best.n = nn; best.mat = mat; best.uv = uv; best.geom = gi; best.tri = tri;
+                    }
+                } else {
+                    blocked = shLight >= 0 ? blocksLight(t, shDist) : blocksEnv(t);
+                }
+                const int next = blocked ? -1 : nextBvhMesh(S, gi + 1);
+                done = false;
+                if (next >= 0) {
+                    gi = next;
+                    travInit(S.geoms[gi], r, tv);
+                    trav = true;
+                    fetch = false;
+                } else if (MODE == TRACE_CLOSEST) {
                     st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
                     st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
                     st.hitTri[pix] = best.tri;
@@ -163,15 +185,15 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                         im[0] += c.x; im[1] += c.y; im[2] += c.z;
                     }
                 }
-                pending = false;
             }
-            if (idle) {
-                const int leader = __builtin_ctzll(idle);
+            const unsigned long long fm = __ballot(fetch);
+            if (fm) {
+                const int leader = __builtin_ctzll(fm);
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(ctr, (uint32_t)__builtin_popcountll(idle));
+                if (lane == leader) base = atomicAdd(ctr, (uint32_t)__builtin_popcountll(fm));
                 base = (uint32_t)__shfl((int)base, leader);
-                if (!trav && !exhausted) {
-                    const uint32_t sidx = base + (uint32_t)__builtin_popcountll(idle & lt);
+                if (fetch) {
+                    const uint32_t sidx = base + (uint32_t)__builtin_popcountll(fm & lt);
                     if (sidx < n) {
                         if (MODE == TRACE_CLOSEST) {
                             pix = bounce == 0 ? (int)sidx : q.q0[sidx];
@@ -184,7 +206,6 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             shDist = o.w;
                             shLight = __float_as_int(d.w);
-                            blocked = false;
                         }
                         gi = firstMesh;
                         travInit(S.geoms[gi], r, tv);
@@ -202,22 +223,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
         if (trav) {
             const DGeom& g = S.geoms[gi];
             bool more = travStep<COUNT>(S.nodes + 8 * (size_t)g.nodeStart, S.triHot + 3 * (size_t)g.triStart, tv, stack, ovRef, ovT, cnt);
-            if (!more) {
-                F3 nn; F2 uv; int mat = 0, tri = -1;
-                float t = travFinish(S, g, r, tv, false, nn, uv, mat, tri);
-                if (COUNT && tv.best >= 0) cnt.meshHits++;
-                if (MODE == TRACE_CLOSEST) {
-                    if (closer(t, gi, best)) {
-                        t = travFinish(S, g, r, tv, true, nn, uv, mat, tri);
-                        best.t = t; best.n = nn; best.mat = mat; best.uv = uv; best.geom = gi; best.tri = tri;
-                    }
-                } else {
-                    blocked = shLight >= 0 ? blocksLight(t, shDist) : blocksEnv(t);
-                }
-                const int next = (MODE == TRACE_SHADOW && blocked) ? -1 : nextBvhMesh(S, gi + 1);
-                if (next >= 0) { gi = next; travInit(S.geoms[gi], r, tv); }
-                else { trav = false; pending = true; }
-            }
+            if (!more) { trav = false; done = true; }
         }
     }
     if (COUNT) flushCounters(cnt, dc, MODE);

@@ -241,6 +241,7 @@ struct MeshTrav {
     int best, bestRank;
     F3 bary;
     int sp, ref;
+    bool fast;                  /* origin and reciprocal direction are finite: no NaN can arise in a slab test */
 };
 
 PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
@@ -254,6 +255,9 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.bary = f3(0.0f);
     tv.sp = 0;
     tv.ref = 0;
+    const float INF = __builtin_inff();
+    tv.fast = __builtin_fabsf(tv.invDir.x) < INF && __builtin_fabsf(tv.invDir.y) < INF && __builtin_fabsf(tv.invDir.z) < INF &&
+              __builtin_fabsf(tv.lo.x) < INF && __builtin_fabsf(tv.lo.y) < INF && __builtin_fabsf(tv.lo.z) < INF;
 }
 
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
@@ -284,8 +288,25 @@ PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* 
             tk[k] = in ? tMin : INF;                                                                 \
             rk[k] = cr;                                                                              \
         }
-        PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
+        /* Without NaNs the hardware min/max give the same values as the compare-and-select forms the
+         * reference's vector library uses (they can differ in the sign of a zero only, which no comparison
+         * below sees), at half the instructions.  A NaN needs 0 * inf, i.e. a non-finite reciprocal. */
+#define PT_CHILD_FAST(k, C)                                                                         \
+        {                                                                                            \
+            float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;                   \
+            float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;                   \
+            float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;                   \
+            float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)), __builtin_fminf(az0, az1)); \
+            float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fmaxf(az0, az1)); \
+            int cr = __float_as_int(rf.C);                                                           \
+            bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);     \
+            tk[k] = in ? tMin : INF;                                                                 \
+            rk[k] = cr;                                                                              \
+        }
+        if (tv.fast) { PT_CHILD_FAST(0, x) PT_CHILD_FAST(1, y) PT_CHILD_FAST(2, z) PT_CHILD_FAST(3, w) }
+        else { PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w) }
 #undef PT_CHILD
+#undef PT_CHILD_FAST
         /* nearest first: 5-exchange network on (distance, ref) */
 #define PT_CSWAP(i, j) { bool sw = tk[j] < tk[i]; float tt_ = sw ? tk[j] : tk[i]; float tu_ = sw ? tk[i] : tk[j]; \
                          int ra_ = sw ? rk[j] : rk[i]; int rb_ = sw ? rk[i] : rk[j]; tk[i] = tt_; tk[j] = tu_; rk[i] = ra_; rk[j] = rb_; }
