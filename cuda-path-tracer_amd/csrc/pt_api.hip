@@ -21,14 +21,15 @@ void pt_set_error(const char* fmt, ...);
 
 void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q);
 void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-                   uint32_t* workCtr, void* dc);
+                   uint32_t* fetchCtr, uint32_t* workCount, void* dc);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
                uint32_t* shadowFetchCtr, uint32_t* shadowCount, void* dc);
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
-void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out, uint32_t* fetchCtr);
+void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out,
+                        uint32_t* fetchCtr, uint32_t* workCount);
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d);
 void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, float* out);
 
@@ -42,11 +43,12 @@ void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, floa
     } while (0)
 
 constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
-constexpr int kMaxBatch = 64;
+constexpr int kMaxBatch = 256;
 /* device work counters, zeroed before every launch group: [section][bounce][batch row] with sections
- * 0 = next slot of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length */
-constexpr int kWorkCtrSection = (PT_MAX_DEPTH + 1) * kMaxBatch;
-constexpr int kWorkCtrCount = 3 * kWorkCtrSection;
+ * 0 = next entry of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length,
+ * 3 = closest-hit work queue length */
+constexpr int kWorkCtrSection = (PT_MAX_DEPTH + 1) * kMaxBatch * kCtrStride;      /* one 128-byte line per counter */
+constexpr int kWorkCtrCount = 4 * kWorkCtrSection;
 
 enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_COUNT };
 
@@ -132,7 +134,7 @@ int allocBatchState(PtContext* c, int batch)
 #define BA(ptr, count, zero) if ((rc = batchAlloc(c, &(ptr), (count), (zero))) != PT_OK) return rc
     BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
     BA(P.hitA, N * B, false); BA(P.hitB, N * B, false); BA(P.hitTri, N * B, false);
-    BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.shQueue, N * B, false);
+    BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.workQueue, N * B, false);
     BA(P.image, N * B * 3, true);
     BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);
     BA(Q.blockHist, (size_t)Q.numBuckets * Q.numBlocks * B, false);
@@ -493,6 +495,8 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
                 nodes = pt_bvh_nodes(built, &nn);
                 idx = pt_bvh_indices(built, &ni);
             }
+            PtBvhNode root{};
+            if (nodes && nn > 0) root = nodes[0];          /* copied: a BVH built here is freed right after flattening */
             rc = flattenMesh(pm.triangles, pm.triangleCount, nodes, nn, idx, ni, fm);
             if (built) pt_bvh_free(built);
             if (rc != PT_OK) { pt_destroy(c); return rc; }
@@ -500,7 +504,24 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
             G.triStart = (int)(allHot.size() / 3);
             G.triCount = pm.triangleCount;
             G.hasBvh = fm.hasBvh ? 1 : 0;
-            if (fm.hasBvh) c->bvhMeshGeoms++;
+            if (fm.hasBvh) {
+                c->bvhMeshGeoms++;
+                /* padded world box of the transformed root box */
+                float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+                for (int corner = 0; corner < 8; ++corner) {
+                    float p[3] = { (corner & 1) ? root.bmax[0] : root.bmin[0], (corner & 2) ? root.bmax[1] : root.bmin[1],
+                                   (corner & 4) ? root.bmax[2] : root.bmin[2] };
+                    for (int k = 0; k < 3; ++k) {        /* column-major 4x4, w = 1 */
+                        float w = g.transform[k] * p[0] + g.transform[4 + k] * p[1] + g.transform[8 + k] * p[2] + g.transform[12 + k];
+                        lo[k] = std::min(lo[k], w); hi[k] = std::max(hi[k], w);
+                    }
+                }
+                float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+                float mag = 0.0f;
+                for (int k = 0; k < 3; ++k) mag = std::max(mag, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+                const float pad = 0.01f * ext + 1e-5f * mag + 1e-6f;
+                for (int k = 0; k < 3; ++k) { G.cullLo[k] = lo[k] - pad; G.cullHi[k] = hi[k] + pad; }
+            }
             /* leafOfOrig is indexed by triStart + original index; keep both arrays aligned */
             size_t ntriFlat = fm.hot.size() / 3;
             allNodes.insert(allNodes.end(), fm.nodes.begin(), fm.nodes.end());
@@ -600,10 +621,11 @@ static int traceBatch(PtContext* c, Batch bt)
     HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
     { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, bt, c->traceDepth, c->state, c->queues); }
     for (int b = 0; b < c->traceDepth; ++b) {
-        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + (size_t)b * kMaxBatch, c->dc); }
+        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + (size_t)b * kMaxBatch * kCtrStride,
+                                                       ctr + 3 * kWorkCtrSection + (size_t)b * kMaxBatch * kCtrStride, c->dc); }
         if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, bt, b, V.numBuckets); }
-        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + kWorkCtrSection + (size_t)b * kMaxBatch,
-                                               ctr + 2 * kWorkCtrSection + (size_t)b * kMaxBatch, c->dc); }
+        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + kWorkCtrSection + (size_t)b * kMaxBatch * kCtrStride,
+                                               ctr + 2 * kWorkCtrSection + (size_t)b * kMaxBatch * kCtrStride, c->dc); }
         { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, bt, b, c->sortOn); }
     }
     ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc);
@@ -726,6 +748,10 @@ int pt_stats(PtContext* c, PtStats* out)
     out->trisTested = h.trav[0][1] + h.trav[1][1];
     out->meshHits = h.trav[0][2] + h.trav[1][2];
     if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] per-ray max: intersect nodes %u tris %u | shade nodes %u tris %u\n", h.maxNodes[0], h.maxTris[0], h.maxNodes[1], h.maxTris[1]);
+    if (getenv("PT_DEBUG_TAIL"))
+        for (int m = 0; m < 2; ++m)
+            fprintf(stderr, "[pt] traversal mode %d: wave iterations %llu, node lanes %llu, leaf lanes %llu, held leaf lanes %llu, refills %llu, refilled lanes %llu\n", m,
+                    h.waveDiag[m][0], h.waveDiag[m][1], h.waveDiag[m][2], h.waveDiag[m][3], h.waveDiag[m][4], h.waveDiag[m][5]);
     out->shadeNodesVisited = h.trav[1][0]; out->shadeTrisTested = h.trav[1][1]; out->shadeMeshHits = h.trav[1][2];
     out->msCamera = c->ms[ST_CAMERA]; out->msIntersect = c->ms[ST_INTERSECT]; out->msSort = c->ms[ST_SORT];
     out->msShade = c->ms[ST_SHADE]; out->msCompact = c->ms[ST_COMPACT];
@@ -762,13 +788,14 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
     SceneView V = c->view;
     V.useBvh = c->useBvh;
     V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
-    uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch;     /* a slot no bounce of a trace uses */
+    uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch * kCtrStride;     /* a slot no bounce of a trace uses */
     for (int first = 0; rc == PT_OK && first < n; first += chunk) {
         const int m = std::min(chunk, n - first);
         hipError_t e = hipMemcpyAsync(dO, origins + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(uint32_t), c->stream);
-        if (e == hipSuccess) { ptl_intersect_rays(c->stream, V, c->state, c->queues, dO, dD, m, dH, ctr); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) { ptl_intersect_rays(c->stream, V, c->state, c->queues, dO, dD, m, dH, ctr, ctr + 3 * kWorkCtrSection); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(out + first, dH, (size_t)m * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); rc = PT_EHIP; }

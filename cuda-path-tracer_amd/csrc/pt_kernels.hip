@@ -24,6 +24,27 @@ namespace ptd {
 PT_DEV int laneId() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 PT_DEV unsigned long long laneMaskLt() { return (1ull << laneId()) - 1ull; }
 
+/* Workgroup-wide append: every thread with flag set gets a distinct index of the list whose length
+ * *counter holds (one atomic per workgroup); -1 for the others.  s_tmp: kBlock / 64 + 1 ints of LDS.
+ * All threads of the workgroup must call it. */
+PT_DEV int blockAppendIndex(bool flag, uint32_t* counter, int* s_tmp)
+{
+    const unsigned long long m = __ballot(flag);
+    const int wave = threadIdx.x >> 6;
+    if (laneId() == 0) s_tmp[wave] = (int)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { int c = s_tmp[w]; s_tmp[w] = total; total += c; }
+        s_tmp[kBlock / 64] = total ? (int)atomicAdd(counter, (uint32_t)total) : 0;
+    }
+    __syncthreads();
+    const int idx = s_tmp[kBlock / 64] + s_tmp[wave] + (int)__builtin_popcountll(m & laneMaskLt());
+    __syncthreads();
+    return flag ? idx : -1;
+}
+
 PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 {
     /* one atomic per wave and counter */
@@ -100,7 +121,11 @@ __global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int t
 #ifndef PT_SHADE_MINWAVES
 #define PT_SHADE_MINWAVES 4
 #endif
+#ifndef PT_LEAF_WAIT
+#define PT_LEAF_WAIT 12
+#endif
 constexpr int kRefillThreshold = PT_REFILL;
+constexpr int kLeafWait = PT_LEAF_WAIT;
 
 PT_DEV int nextBvhMesh(const SceneView& S, int from)
 {
@@ -111,19 +136,48 @@ PT_DEV int nextBvhMesh(const SceneView& S, int from)
 
 enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1 };
 
-/* items: TRACE_CLOSEST -> queue slots [0, live[bounce]); TRACE_SHADOW -> shadow queue [0, *shadowCount) */
+/* Work list of the closest-hit traversal: rays that may hit a BVH mesh go to the work queue (one
+ * atomic per wave; the order is free, results are stored by pixel), all others get their "no mesh
+ * hit" record here.  Most rays of a typical bounce never come near a mesh; keeping them out of the
+ * traversal kernel keeps its lanes busy with rays that actually walk a tree. */
+__global__ void __launch_bounds__(kBlock) k_cull(SceneView S, PathState st, Queues q, int bounce, uint32_t* workCount)
+{
+    __shared__ int s_tmp[kBlock / 64 + 1];
+    st = st.at(blockIdx.y);
+    q = q.at(blockIdx.y);
+    const uint32_t n = q.live[bounce];
+    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    bool cand = false;
+    int pix = 0;
+    if ((uint32_t)slot < n) {
+        pix = bounce == 0 ? slot : q.q0[slot];
+        float4 o = st.rayO[pix], d = st.rayD[pix];
+        Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+        cand = mayHitBvhMeshes(S, r, __builtin_inff());
+        if (!cand) {
+            st.hitA[pix] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+            st.hitB[pix] = make_float4(__int_as_float(0), 0.0f, 0.0f, __int_as_float(-1));
+            st.hitTri[pix] = -1;
+        }
+    }
+    const int idx = blockAppendIndex(cand, workCount + blockIdx.y * kCtrStride, s_tmp);
+    if (idx >= 0) st.workQueue[idx] = pix;
+}
+
+/* items: work queue entries [0, workCount[row]) */
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S, PathState st, Queues q, int bounce,
-                                                                     uint32_t* fetchCtr, const uint32_t* shadowCount, DevCounters* dc)
+                                                                     uint32_t* fetchCtr, const uint32_t* workCount, DevCounters* dc)
 {
     __shared__ int s_stack[kStackDepth * kBlock];
     const int tid = threadIdx.x;
     const int lane = laneId();
     st = st.at(blockIdx.y);
     q = q.at(blockIdx.y);
-    const uint32_t n = MODE == TRACE_CLOSEST ? q.live[bounce] : shadowCount[blockIdx.y];
+    const uint32_t n = workCount[blockIdx.y * kCtrStride];
     if (n == 0) return;
-    uint32_t* ctr = fetchCtr + blockIdx.y;
+    uint32_t* ctr = fetchCtr + blockIdx.y * kCtrStride;
     int* stack = s_stack + tid;
     int ovRef[kOverflowStack];
     float ovT[kOverflowStack];
@@ -141,6 +195,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
 
     while (true) {
         const unsigned long long idle = __ballot(!trav && !exhausted);
@@ -187,6 +242,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 }
             }
             const unsigned long long fm = __ballot(fetch);
+            if (COUNT) { diag[4]++; diag[5] += __builtin_popcountll(fm); }
             if (fm) {
                 const int leader = __builtin_ctzll(fm);
                 uint32_t base = 0;
@@ -196,12 +252,12 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     const uint32_t sidx = base + (uint32_t)__builtin_popcountll(fm & lt);
                     if (sidx < n) {
                         if (MODE == TRACE_CLOSEST) {
-                            pix = bounce == 0 ? (int)sidx : q.q0[sidx];
+                            pix = st.workQueue[sidx];
                             float4 o = st.rayO[pix], d = st.rayD[pix];
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
                         } else {
-                            pix = st.shQueue[sidx];
+                            pix = st.workQueue[sidx];
                             float4 o = st.shO[pix], d = st.shD[pix];
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             shDist = o.w;
@@ -220,13 +276,26 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 continue;
             }
         }
+        /* leaves wait until kLeafWait lanes hold one (or no lane has a node left): triangle tests then
+         * run with fuller waves */
+        const unsigned long long nodeLanes = __ballot(trav && tv.ref >= 0);
+        const unsigned long long leafLanes = __ballot(trav && tv.ref < 0);
+        const bool leafTurn = nodeLanes == 0 || __builtin_popcountll(leafLanes) >= kLeafWait;
+        if (COUNT) {
+            diag[0]++; diag[1] += __builtin_popcountll(nodeLanes);
+            diag[leafTurn ? 2 : 3] += __builtin_popcountll(leafLanes);
+        }
         if (trav) {
             const DGeom& g = S.geoms[gi];
-            bool more = travStep<COUNT>(S.nodes + 8 * (size_t)g.nodeStart, S.triHot + 3 * (size_t)g.triStart, tv, stack, ovRef, ovT, cnt);
+            bool more = travStep<COUNT>(S.nodes + 8 * (size_t)g.nodeStart, S.triHot + 3 * (size_t)g.triStart, tv, stack, ovRef, ovT, cnt, leafTurn);
             if (!more) { trav = false; done = true; }
         }
     }
-    if (COUNT) flushCounters(cnt, dc, MODE);
+    if (COUNT) {
+        flushCounters(cnt, dc, MODE);
+        if (lane == 0)
+            for (int i = 0; i < 6; ++i) atomicAdd(&dc->waveDiag[MODE][i], diag[i]);
+    }
 }
 
 /* fold the inline geoms into the mesh result; final hit record, sort bucket, bucket histogram */
@@ -394,6 +463,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
                                                                      uint32_t* shadowCount, DevCounters* dc)
 {
     __shared__ int s_alive[kBlock / 64];
+    __shared__ int s_tmp[kBlock / 64 + 1];
     st = st.at(blockIdx.y);
     q = q.at(blockIdx.y);
     const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
@@ -432,21 +502,13 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         }
         queue[slot] = alive ? pix : (-1 - pix);
     }
-    /* shadow queue append: one atomic per wave */
-    {
-        unsigned long long pm = __ballot(sq.pending);
-        if (pm) {
-            const int leader = __builtin_ctzll(pm);
-            uint32_t base = 0;
-            if (laneId() == leader) base = atomicAdd(shadowCount + blockIdx.y, (uint32_t)__builtin_popcountll(pm));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (sq.pending) {
-                st.shQueue[base + (uint32_t)__builtin_popcountll(pm & laneMaskLt())] = pix;
-                st.shO[pix] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
-                st.shD[pix] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
-                st.shC[pix] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, 0.0f);
-            }
-        }
+    /* shadow queue append */
+    const int shIdx = blockAppendIndex(sq.pending, shadowCount + blockIdx.y * kCtrStride, s_tmp);
+    if (shIdx >= 0) {
+        st.workQueue[shIdx] = pix;
+        st.shO[pix] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
+        st.shD[pix] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
+        st.shC[pix] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, 0.0f);
     }
     if (COUNT) flushCounters(cnt, dc, 1);
     unsigned long long m = __ballot(alive);
@@ -645,12 +707,13 @@ static inline int persistentGridX(int batch)
     return x < 1 ? 1 : x;
 }
 void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-                   uint32_t* fetchCtr, void* dc)
+                   uint32_t* fetchCtr, uint32_t* workCount, void* dc)
 {
     if (S.numBvhMeshes > 0) {
+        hipLaunchKernelGGL(k_cull, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, workCount);
         dim3 grid(persistentGridX(bt.count), bt.count);
-        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)nullptr, (DevCounters*)dc);
-        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)nullptr, (DevCounters*)dc);
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)workCount, (DevCounters*)dc);
+        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)workCount, (DevCounters*)dc);
     }
     if (count) hipLaunchKernelGGL(k_prims<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
     else hipLaunchKernelGGL(k_prims<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
@@ -689,11 +752,12 @@ void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rg
     hipLaunchKernelGGL(k_display, dim3(gridFor(n)), dim3(kBlock), 0, s, image, n, iter, rgba);
 }
 /* n <= st.numPixels rays through the production intersect stage (row 0 of the path state) */
-void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out, uint32_t* fetchCtr)
+void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out,
+                        uint32_t* fetchCtr, uint32_t* workCount)
 {
     hipLaunchKernelGGL(k_import_rays, dim3(gridFor(n)), dim3(kBlock), 0, s, st, q, n, o, d);
     Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
-    ptl_intersect(s, S, st, q, bt, 0, 0, false, fetchCtr, nullptr);
+    ptl_intersect(s, S, st, q, bt, 0, 0, false, fetchCtr, workCount, nullptr);
     hipLaunchKernelGGL(k_export_hits, dim3(gridFor(n)), dim3(kBlock), 0, s, st, n, out);
 }
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d)

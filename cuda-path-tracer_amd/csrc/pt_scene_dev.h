@@ -34,6 +34,8 @@ constexpr int kStackDepth = 2 * kLdsStack; /* LDS dwords per lane               
 constexpr int kOverflowStack = 64;   /* further entries per ray in private memory, touched only past kLdsStack */
 constexpr int kEmptyRef = 0x7fffffff;
 constexpr int kLeafMaxTris = 32;     /* triangles addressable by one leaf reference            */
+constexpr int kCtrStride = 32;        /* dwords between work counters: one 128-byte line each, so that atomics on
+                                         different counters do not queue up on one line */
 constexpr int kMaxBuckets = 256;     /* material ids + the miss bucket handled by the sort   */
 
 struct DGeom {
@@ -42,8 +44,12 @@ struct DGeom {
     float T[16], I[16], IT[16];
     float translation[3], pad1;
     float scale[3], pad2;
+    /* BVH meshes: world-space box around the transformed root box, padded by a percent of its size.
+     * A ray that misses it by the plain slab test cannot pass any leaf box of the mesh. */
+    float cullLo[3], pad3;
+    float cullHi[3], pad4;
 };
-static_assert(sizeof(DGeom) == 256, "DGeom layout");
+static_assert(sizeof(DGeom) == 288, "DGeom layout");
 
 struct DTexture { const uint8_t* data; int width, height, components, pad; };
 struct DLight { int geomIdx; float area; float pdf; };
@@ -83,14 +89,15 @@ struct PathState {
     float4* shO;
     float4* shD;
     float4* shC;
-    int* shQueue;                   /* pixels with a pending shadow ray, in arrival order */
+    int* workQueue;                 /* pixels the traversal kernel has to visit, in arrival order: rays that may hit a
+                                       BVH mesh before shading, pending shadow rays after it */
     size_t numPixels;
     PT_DEV PathState at(int k) const
     {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
         r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.image += 3 * off;
-        r.hitTri += off; r.shO += off; r.shD += off; r.shC += off; r.shQueue += off;
+        r.hitTri += off; r.shO += off; r.shD += off; r.shC += off; r.workQueue += off;
         return r;
     }
 };
@@ -123,6 +130,7 @@ struct DevCounters {
     unsigned long long pathBounces;
     unsigned long long trav[2][3];      /* [0] intersect stage, [1] shade stage: nodes, triangles, mesh hits */
     unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
+    unsigned long long waveDiag[2][6];  /* per traversal mode: wave iterations, node-step lanes, leaf-step lanes, held-leaf lanes, refills, refilled lanes */
     uint32_t lastLive[PT_MAX_DEPTH + 2];
 };
 
@@ -263,7 +271,8 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
  * closer-or-equal hit.  Returns false when the stack has run dry. */
 template <bool COUNT>
-PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt)
+PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt,
+                     bool leafTurn = true)
 {
     const float INF = __builtin_inff();
     const int ref = tv.ref;
@@ -323,6 +332,7 @@ PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* 
         tv.sp = sp;
         if (tk[0] < INF) { tv.ref = rk[0]; return true; }
     } else {
+        if (!leafTurn) return true;     /* hold the leaf until enough lanes of the wave have one */
         const unsigned x = ~(unsigned)ref;
         const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
         for (int i = 0; i < count; ++i) {
@@ -433,6 +443,26 @@ PT_DEV float inlineOccluderDistance(const SceneView& S, const DGeom& g, const Ra
     if (g.type == PT_CUBE) return hitBox(g, r, n);
     if (g.type == PT_GLTF_MESH) return hitMeshLinear<COUNT>(S, g, r, false, n, uv, m, tri, cnt);
     return -1.0f;
+}
+
+/* Conservative pre-test against the padded world boxes of the BVH meshes: false only when the ray
+ * (up to distance maxDist along it, in units of |d|) certainly misses all of them.  Every comparison
+ * is false on NaN and the min/max ignore a NaN operand, so odd rays are kept. */
+PT_DEV bool mayHitBvhMeshes(const SceneView& S, const Ray& r, float maxDist)
+{
+    const F3 inv = 1.0f / r.d;
+    for (int i = 0; i < S.numGeoms; ++i) {
+        const DGeom& g = S.geoms[i];
+        if (!isBvhMesh(S, g)) continue;
+        float x0 = (g.cullLo[0] - r.o.x) * inv.x, x1 = (g.cullHi[0] - r.o.x) * inv.x;
+        float y0 = (g.cullLo[1] - r.o.y) * inv.y, y1 = (g.cullHi[1] - r.o.y) * inv.y;
+        float z0 = (g.cullLo[2] - r.o.z) * inv.z, z1 = (g.cullHi[2] - r.o.z) * inv.z;
+        float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+        float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        const bool miss = (tMax < tMin) || (tMax < 0.0f) || (tMin > maxDist);
+        if (!miss) return true;
+    }
+    return false;
 }
 
 /* occlusion rules of the two shadow tests, per geom (src/pathtrace.cu:2222 and :2293) */
@@ -687,7 +717,7 @@ PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 mat
             if (NdotL > 0.0f) {
                 Ray sh; sh.o = P + normal * 0.001f; sh.d = wi;
                 if (lightVisibleInline<COUNT>(S, sh, L.geomIdx, dist, cnt)) {
-                    if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = dist; sq.lightGeom = L.geomIdx; }
+                    if (S.numBvhMeshes > 0 && mayHitBvhMeshes(S, sh, dist * 1.001f)) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = dist; sq.lightGeom = L.geomIdx; }
                     F3 ln = normalize(lp - f3(lg.translation));
                     float NdotLl = nanMax(0.0f, dot(-wi, ln));
                     float pdfLight = 1.0f / (nanMax(L.area, 0.01f) * nl);
@@ -710,7 +740,7 @@ PT_DEV void shadeDiffuse(const SceneView& S, Path& p, float t, F3 normal, F3 mat
         if (NdotL > 0.0f) {
             Ray sh; sh.o = P + normal * 0.001f; sh.d = ed;
             if (envVisibleInline<COUNT>(S, sh, cnt)) {
-                if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = 0.0f; sq.lightGeom = -1; }
+                if (S.numBvhMeshes > 0 && mayHitBvhMeshes(S, sh, __builtin_inff())) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = 0.0f; sq.lightGeom = -1; }
                 float pdfBRDF = NdotL / kPI;
                 float sum = ep + pdfBRDF;
                 float weight = ep / nanMax(sum, MIN_PDF);
@@ -967,7 +997,7 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
             if (NdotL > 0.0f) {
                 Ray sh; sh.o = P + normal * 0.001f; sh.d = wi;
                 if (lightVisibleInline<COUNT>(S, sh, L.geomIdx, dist, cnt)) {
-                    if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = dist; sq.lightGeom = L.geomIdx; }
+                    if (S.numBvhMeshes > 0 && mayHitBvhMeshes(S, sh, dist * 1.001f)) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = dist; sq.lightGeom = L.geomIdx; }
                     float D, NdotH, VdotH;
                     F3 brdf = pbrBrdf(normal, wo, wi, NdotL, rough, metallic, albedo, F0, D, NdotH, VdotH);
                     F3 ln = normalize(lp - f3(lg.translation));
@@ -991,7 +1021,7 @@ PT_DEV void shadePbr(const SceneView& S, Path& p, float t, F3 normal, const PtMa
         if (NdotL > 0.0f) {
             Ray sh; sh.o = P + normal * 0.001f; sh.d = ed;
             if (envVisibleInline<COUNT>(S, sh, cnt)) {
-                if (S.numBvhMeshes > 0) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = 0.0f; sq.lightGeom = -1; }
+                if (S.numBvhMeshes > 0 && mayHitBvhMeshes(S, sh, __builtin_inff())) { sq.pending = true; sq.o = sh.o; sq.d = sh.d; sq.dist = 0.0f; sq.lightGeom = -1; }
                 float D, NdotH, VdotH;
                 F3 brdf = pbrBrdf(normal, wo, ed, NdotL, rough, metallic, albedo, F0, D, NdotH, VdotH);
                 float pdfBRDF = (NdotL / kPI) * (1.0f - metallic) + (D * NdotH / (4.0f * VdotH)) * metallic;
