@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 using namespace ptd;
@@ -296,9 +297,10 @@ struct Flattener {
     int newNode4()
     {
         int id = (int)(fm.nodes.size() / 8);
-        const float big = 3.402823466e+38f;
-        for (int k = 0; k < 3; ++k) fm.nodes.push_back(make_float4(big, big, big, big));
-        for (int k = 0; k < 3; ++k) fm.nodes.push_back(make_float4(-big, -big, -big, -big));
+        /* an empty slot is a box at +infinity: its slab distances are infinite, so the plain test rejects it
+         * (entry beyond any hit, or exit behind the origin) without a look at the reference word */
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int k = 0; k < 6; ++k) fm.nodes.push_back(make_float4(inf, inf, inf, inf));
         fm.nodes.push_back(make_float4(asF(kEmptyRef), asF(kEmptyRef), asF(kEmptyRef), asF(kEmptyRef)));
         fm.nodes.push_back(make_float4(0, 0, 0, 0));
         return id;

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int t
 #define PT_SHADE_MINWAVES 4
 #endif
 #ifndef PT_LEAF_WAIT
-#define PT_LEAF_WAIT 12
+#define PT_LEAF_WAIT 16
 #endif
 constexpr int kRefillThreshold = PT_REFILL;
 constexpr int kLeafWait = PT_LEAF_WAIT;
@@ -286,8 +286,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
             diag[leafTurn ? 2 : 3] += __builtin_popcountll(leafLanes);
         }
         if (trav) {
-            const DGeom& g = S.geoms[gi];
-            bool more = travStep<COUNT>(S.nodes + 8 * (size_t)g.nodeStart, S.triHot + 3 * (size_t)g.triStart, tv, stack, ovRef, ovT, cnt, leafTurn);
+            bool more = travStep<COUNT>(S, tv, stack, ovRef, ovT, cnt, leafTurn);
             if (!more) { trav = false; done = true; }
         }
     }

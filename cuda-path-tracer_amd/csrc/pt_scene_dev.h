@@ -249,6 +249,8 @@ struct MeshTrav {
     int best, bestRank;
     F3 bary;
     int sp, ref;
+    int nodeStart, triStart;    /* of the mesh being walked, kept in registers: a per-step reload from the geom
+                                   record would put one more dependent memory access in front of every node fetch */
     bool fast;                  /* origin and reciprocal direction are finite: no NaN can arise in a slab test */
 };
 
@@ -263,6 +265,8 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.bary = f3(0.0f);
     tv.sp = 0;
     tv.ref = 0;
+    tv.nodeStart = g.nodeStart;
+    tv.triStart = g.triStart;
     const float INF = __builtin_inff();
     tv.fast = __builtin_fabsf(tv.invDir.x) < INF && __builtin_fabsf(tv.invDir.y) < INF && __builtin_fabsf(tv.invDir.z) < INF &&
               __builtin_fabsf(tv.lo.x) < INF && __builtin_fabsf(tv.lo.y) < INF && __builtin_fabsf(tv.lo.z) < INF;
@@ -271,13 +275,12 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
  * closer-or-equal hit.  Returns false when the stack has run dry. */
 template <bool COUNT>
-PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt,
-                     bool leafTurn = true)
+PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt, bool leafTurn = true)
 {
     const float INF = __builtin_inff();
     const int ref = tv.ref;
     if (ref >= 0) {
-        const float4* q = nodes + 8 * (size_t)ref;
+        const float4* q = S.nodes + 8 * ((size_t)tv.nodeStart + (size_t)ref);
         float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
         float4 rf = q[6];
         if (COUNT) cnt.nodes++;
@@ -307,10 +310,9 @@ PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* 
             float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;                   \
             float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)), __builtin_fminf(az0, az1)); \
             float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fmaxf(az0, az1)); \
-            int cr = __float_as_int(rf.C);                                                           \
-            bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);     \
+            bool in = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);   /* empty slots fail: boxes at +inf */ \
             tk[k] = in ? tMin : INF;                                                                 \
-            rk[k] = cr;                                                                              \
+            rk[k] = __float_as_int(rf.C);                                                            \
         }
         if (tv.fast) { PT_CHILD_FAST(0, x) PT_CHILD_FAST(1, y) PT_CHILD_FAST(2, z) PT_CHILD_FAST(3, w) }
         else { PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w) }
@@ -337,7 +339,7 @@ PT_DEV bool travStep(const float4* nodes, const float4* hot, MeshTrav& tv, int* 
         const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
         for (int i = 0; i < count; ++i) {
             F3 bary;
-            const float4* tp = hot + 3 * (size_t)(first + i);
+            const float4* tp = S.triHot + 3 * ((size_t)tv.triStart + (size_t)(first + i));
             float tt = hitTriangle(tp, tv.lo, tv.ld, bary);
             if (COUNT) cnt.tris++;
             if (tt > 0.0f && !(tt > tv.closestT)) {
