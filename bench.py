@@ -35,18 +35,19 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sort", action="store_true", help="MATERIAL_SORTING 0")
     ap.add_argument("--cpu-spp", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="iterations sharing one launch group (0 = library default)")
+    ap.add_argument("--batch", type=int, default=0, help="iterations sharing one launch group (0 = min(steps, 64))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,8 +89,8 @@ def main():
         return 1 + rank + step * world
 
     # ---- untimed: warmup, then a counted pass over the timed iterations (exact node / triangle counts)
-    if args.batch:
-        tr.set_option(pt.PT_OPT_BATCH, args.batch)
+    batch = args.batch if args.batch else max(1, min(args.steps, 64))
+    tr.set_option(pt.PT_OPT_BATCH, batch)
     if args.warmup:
         tr.trace_range(it_index(0), it_index(args.warmup), world)
     barrier()
@@ -99,8 +100,9 @@ def main():
     count_steps = min(args.steps, 4)
     tr.trace_range(it_index(args.warmup), it_index(args.warmup + count_steps), world)
     cs = tr.stats()
-    counted = dict(pb=cs.pathBounces, V=cs.nodesVisited, T=cs.trisTested, H=cs.meshHits,
-                   Vs=cs.shadeNodesVisited, Ts=cs.shadeTrisTested, Hs=cs.shadeMeshHits)
+    counted = dict(pb=cs.pathBounces, rays=cs.tracedRays, shadow_rays=cs.shadowRays,
+                   boxes=cs.boxesTested - cs.shadeBoxesTested, tris=cs.trisTested - cs.shadeTrisTested, hits=cs.meshHits - cs.shadeMeshHits,
+                   s_boxes=cs.shadeBoxesTested, s_tris=cs.shadeTrisTested)
     tr.set_option(pt.PT_OPT_COUNTERS, 0)
     tr.reset_stats()
     tr.clear()
@@ -128,37 +130,43 @@ def main():
     out = None
     if rank == 0:
         value = total_pb / elapsed / 1e6
-        # ---- roofline of the dominant kernel (by accumulated HIP-event time)
-        stages = {"k_intersect": st.msIntersect, "k_shade": st.msShade, "sort": st.msSort, "compact": st.msCompact}
-        per_pb = 1.0 / max(counted["pb"], 1)
-        Vi, Ti, Hi = (counted["V"] - counted["Vs"]) * per_pb, (counted["T"] - counted["Ts"]) * per_pb, (counted["H"] - counted["Hs"]) * per_pb
-        Vs, Ts, Hs = counted["Vs"] * per_pb, counted["Ts"] * per_pb, counted["Hs"] * per_pb
-        # algorithmic bytes per path-bounce = the stage's share of the 192 streaming bytes (path state read and
-        # written once = 96, hit record written and read once = 56, sort key + index written and read once = 16,
-        # image read-modify-write = 24) + 32 B per BVH node visited + 36 B per triangle tested + 64 B of
-        # attributes per mesh hit (none for shadow queries)
-        b_int = 84.0 + 32.0 * Vi + 36.0 * Ti + 64.0 * Hi        # path read 48 + hit written 28 + key/index written 8
-        b_shade = 108.0 + 32.0 * Vs + 36.0 * Ts                 # path written 48 + hit read 28 + key/index read 8 + image 24
-        dominant = "k_intersect" if st.msIntersect >= st.msShade else "k_shade"
-        b_dom = b_int if dominant == "k_intersect" else b_shade
-        ms_dom = stages[dominant]
-        launches = st.launchesIntersect if dominant == "k_intersect" else st.launchesShade
-        units_per_launch = st.pathBounces / max(launches, 1)
-        avg_ms = ms_dom / max(launches, 1)
-        achieved = (b_dom * units_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # ---- roofline of the dominant kernel (by accumulated HIP-event time): the BVH traversal kernel in
+        # closest-hit mode.  Algorithmic bytes per path-bounce of the whole loop = 192 streaming bytes
+        # (path state read + written 96, hit record written + read 56, sort key + index 16, image 24)
+        # + 32 B per child box tested + 36 B per triangle tested + 64 B of attributes per mesh hit.
+        # The traversal kernel's share, per ray it is handed: 4 B queue entry + 48 B path state read
+        # + 28 B hit record written, plus its own box / triangle / attribute bytes (exact counts from
+        # the counted pass over the first iterations of the timed range).
+        stages = {"k_trace(closest)": st.msTrace, "k_trace(shadow)": st.msShadowTrace,
+                  "intersect_other(k_cull+k_prims)": st.msIntersect - st.msTrace,
+                  "k_shade": st.msShade - st.msShadowTrace, "sort": st.msSort, "compact": st.msCompact}
+        per_ray = 1.0 / max(counted["rays"], 1)
+        boxes, tris, hits = counted["boxes"] * per_ray, counted["tris"] * per_ray, counted["hits"] * per_ray
+        b_ray = 80.0 + 32.0 * boxes + 36.0 * tris + 64.0 * hits
+        rays_per_launch = st.tracedRays / max(st.launchesTrace, 1)
+        avg_ms = st.msTrace / max(st.launchesTrace, 1)
+        achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # fp32 VALU view of the same kernel: 30 flop per box, 53 per triangle, 36 + 120 per ray (set-up, epilogue)
+        flops_ray = 30.0 * boxes + 53.0 * tris + 36.0 + 120.0 * hits
+        valu_tflops = (flops_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        b_loop = 192.0 + (32.0 * (counted["boxes"] + counted["s_boxes"]) + 36.0 * (counted["tris"] + counted["s_tris"])
+                          + 64.0 * counted["hits"]) / max(counted["pb"], 1)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant)
+                traffic = json.load(open(tpath)).get("k_trace(closest)")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "alg_bytes_per_path_bounce": round(b_dom, 1), "units_per_launch": round(units_per_launch, 1),
-                    "avg_launch_ms": round(avg_ms, 5),
-                    "nodes_per_path_bounce": round(Vi if dominant == "k_intersect" else Vs, 2),
-                    "tris_per_path_bounce": round(Ti if dominant == "k_intersect" else Ts, 2),
+                    "alg_bytes_per_ray": round(b_ray, 1), "rays_per_launch": round(rays_per_launch, 1),
+                    "avg_launch_ms": round(avg_ms, 5), "launches": st.launchesTrace,
+                    "boxes_per_ray": round(boxes, 2), "tris_per_ray": round(tris, 2), "mesh_hit_rate": round(hits, 3),
+                    "valu_fp32_tflops": round(valu_tflops, 2), "valu_fp32_peak_tflops": VALU_PEAK_TFLOPS,
+                    "valu_frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
+                    "loop_alg_bytes_per_path_bounce": round(b_loop, 1),
+                    "loop_alg_gbs": round(b_loop * total_pb / world / elapsed / 1e9, 1),
                     "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stages.items()}}
 
         cpu = None
@@ -182,7 +190,7 @@ def main():
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": desc, "resolution": list(res), "depth": depth, "spp_per_step_per_gpu": 1,
-                          "material_sort": not args.no_sort, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
+                          "material_sort": not args.no_sort, "iterations_per_launch_group": batch, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
                           "path_bounces_per_spp": round(st.pathBounces / max(args.steps, 1), 1)},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

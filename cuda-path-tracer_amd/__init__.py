@@ -94,7 +94,11 @@ class PtStats(C.Structure):
                 ("msIntersect", C.c_float), ("msSort", C.c_float), ("msShade", C.c_float),
                 ("msCompact", C.c_float), ("msCamera", C.c_float),
                 ("launchesIntersect", C.c_uint32), ("launchesShade", C.c_uint32),
-                ("shadeNodesVisited", C.c_uint64), ("shadeTrisTested", C.c_uint64), ("shadeMeshHits", C.c_uint64)]
+                ("shadeNodesVisited", C.c_uint64), ("shadeTrisTested", C.c_uint64), ("shadeMeshHits", C.c_uint64),
+                ("msTrace", C.c_float), ("msShadowTrace", C.c_float),
+                ("launchesTrace", C.c_uint32), ("launchesShadowTrace", C.c_uint32),
+                ("tracedRays", C.c_uint64), ("shadowRays", C.c_uint64),
+                ("boxesTested", C.c_uint64), ("shadeBoxesTested", C.c_uint64)]
 
 
 class PtError(RuntimeError):

@@ -21,16 +21,19 @@ using namespace ptd;
 void pt_set_error(const char* fmt, ...);
 
 void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q);
-void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-                   uint32_t* fetchCtr, uint32_t* workCount, void* dc);
+void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount);
+void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
+               uint32_t* fetchCtr, const uint32_t* workCount, void* dc);
+void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-               uint32_t* shadowFetchCtr, uint32_t* shadowCount, void* dc);
+               uint32_t* shadowCount, void* dc);
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
-void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc);
+void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
+                const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
-void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out,
-                        uint32_t* fetchCtr, uint32_t* workCount);
+void ptl_import_rays(hipStream_t s, PathState st, Queues q, const float* o, const float* d, int n);
+void ptl_export_hits(hipStream_t s, PathState st, int n, PtHit* out);
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d);
 void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, float* out);
 
@@ -51,7 +54,7 @@ constexpr int kMaxBatch = 256;
 constexpr int kWorkCtrSection = (PT_MAX_DEPTH + 1) * kMaxBatch * kCtrStride;      /* one 128-byte line per counter */
 constexpr int kWorkCtrCount = 4 * kWorkCtrSection;
 
-enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_COUNT };
+enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_TRACE, ST_SHADOW_TRACE, ST_COUNT };   /* the last two nest inside intersect / shade */
 
 struct TimedSpan { hipEvent_t a, b; int stage; };
 
@@ -79,8 +82,8 @@ struct PtContext {
     uint64_t iterations = 0;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> freeEvents;
-    float ms[ST_COUNT] = { 0, 0, 0, 0, 0 };
-    uint32_t launches[ST_COUNT] = { 0, 0, 0, 0, 0 };
+    float ms[ST_COUNT] = {};
+    uint32_t launches[ST_COUNT] = {};
 };
 
 namespace {
@@ -622,15 +625,34 @@ static int traceBatch(PtContext* c, Batch bt)
     uint32_t* ctr = c->workCtr;
     HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
     { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, bt, c->traceDepth, c->state, c->queues); }
+    uint32_t* closestFetch = ctr;
+    uint32_t* shadowFetch = ctr + kWorkCtrSection;
+    uint32_t* shadowCount = ctr + 2 * kWorkCtrSection;
+    uint32_t* closestCount = ctr + 3 * kWorkCtrSection;
+    const bool meshes = V.numBvhMeshes > 0;
     for (int b = 0; b < c->traceDepth; ++b) {
-        { SpanGuard g(c, ST_INTERSECT); ptl_intersect(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + (size_t)b * kMaxBatch * kCtrStride,
-                                                       ctr + 3 * kWorkCtrSection + (size_t)b * kMaxBatch * kCtrStride, c->dc); }
+        const size_t row = (size_t)b * kMaxBatch * kCtrStride;
+        {
+            SpanGuard g(c, ST_INTERSECT);
+            if (meshes) {
+                ptl_cull(s, V, c->state, c->queues, bt, b, closestCount + row);
+                SpanGuard t(c, ST_TRACE);
+                ptl_trace(s, V, c->state, c->queues, bt, b, false, count, closestFetch + row, closestCount + row, c->dc);
+            }
+            ptl_prims(s, V, c->state, c->queues, bt, b, c->sortOn, count, c->dc);
+        }
         if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, bt, b, V.numBuckets); }
-        { SpanGuard g(c, ST_SHADE); ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, ctr + kWorkCtrSection + (size_t)b * kMaxBatch * kCtrStride,
-                                               ctr + 2 * kWorkCtrSection + (size_t)b * kMaxBatch * kCtrStride, c->dc); }
+        {
+            SpanGuard g(c, ST_SHADE);
+            ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, shadowCount + row, c->dc);
+            if (meshes) {
+                SpanGuard t(c, ST_SHADOW_TRACE);
+                ptl_trace(s, V, c->state, c->queues, bt, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
+            }
+        }
         { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, bt, b, c->sortOn); }
     }
-    ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc);
+    ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc, shadowCount, closestCount, kMaxBatch);
     HIP_TRY(hipGetLastError());
     c->iterations += (uint64_t)bt.count;
     return PT_OK;
@@ -758,6 +780,10 @@ int pt_stats(PtContext* c, PtStats* out)
     out->msCamera = c->ms[ST_CAMERA]; out->msIntersect = c->ms[ST_INTERSECT]; out->msSort = c->ms[ST_SORT];
     out->msShade = c->ms[ST_SHADE]; out->msCompact = c->ms[ST_COMPACT];
     out->launchesIntersect = c->launches[ST_INTERSECT]; out->launchesShade = c->launches[ST_SHADE];
+    out->msTrace = c->ms[ST_TRACE]; out->msShadowTrace = c->ms[ST_SHADOW_TRACE];
+    out->launchesTrace = c->launches[ST_TRACE]; out->launchesShadowTrace = c->launches[ST_SHADOW_TRACE];
+    out->tracedRays = h.workItems[0]; out->shadowRays = h.workItems[1];
+    out->boxesTested = h.trav[0][3] + h.trav[1][3]; out->shadeBoxesTested = h.trav[1][3];
     return PT_OK;
 }
 
@@ -797,7 +823,17 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
         if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream);
-        if (e == hipSuccess) { ptl_intersect_rays(c->stream, V, c->state, c->queues, dO, dD, m, dH, ctr, ctr + 3 * kWorkCtrSection); e = hipGetLastError(); }
+        if (e == hipSuccess) {
+            Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
+            ptl_import_rays(c->stream, c->state, c->queues, dO, dD, m);
+            if (V.numBvhMeshes > 0) {
+                ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection);
+                ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, ctr, ctr + 3 * kWorkCtrSection, nullptr);
+            }
+            ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr);
+            ptl_export_hits(c->stream, c->state, m, dH);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(out + first, dH, (size_t)m * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); rc = PT_EHIP; }

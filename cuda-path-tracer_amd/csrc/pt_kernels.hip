@@ -48,18 +48,20 @@ PT_DEV int blockAppendIndex(bool flag, uint32_t* counter, int* s_tmp)
 PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 {
     /* one atomic per wave and counter */
-    unsigned n = c.nodes, t = c.tris, h = c.meshHits;
+    unsigned n = c.nodes, t = c.tris, h = c.meshHits, b = c.boxes;
     atomicMax(&dc->maxNodes[stage], n);
     atomicMax(&dc->maxTris[stage], t);
     for (int off = 32; off > 0; off >>= 1) {
         n += __shfl_down(n, off);
         t += __shfl_down(t, off);
         h += __shfl_down(h, off);
+        b += __shfl_down(b, off);
     }
     if (laneId() == 0) {
         if (n) atomicAdd(&dc->trav[stage][0], (unsigned long long)n);
         if (t) atomicAdd(&dc->trav[stage][1], (unsigned long long)t);
         if (h) atomicAdd(&dc->trav[stage][2], (unsigned long long)h);
+        if (b) atomicAdd(&dc->trav[stage][3], (unsigned long long)b);
     }
 }
 
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     int shLight = -1;           /* shadow mode: geom of the light, -1 for an environment ray */
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
     unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
 
     while (true) {
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
         __syncthreads();
     }
     const bool active = (uint32_t)slot < n;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
     int key = 0;
     if (active) {
         const int pix = bounce == 0 ? slot : q.q0[slot];
@@ -472,7 +474,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     const int slot = blockIdx.x * kBlock + tid;
     const bool active = (uint32_t)slot < n;
     int* queue = sortOn ? q.q1 : q.q0;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
     bool alive = false;
     ShadowReq sq;
     sq.pending = false; sq.o = f3(0.0f); sq.d = f3(0.0f); sq.dist = 0.0f; sq.lightGeom = -1; sq.colorVisible = f3(0.0f);
@@ -587,10 +589,17 @@ __global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q,
 }
 
 /* per-batch bookkeeping: path-bounce total over the batch, live curve of its last iteration */
-__global__ void k_finish(Queues q0, int depth, int batch, DevCounters* dc)
+__global__ void k_finish(Queues q0, int depth, int batch, DevCounters* dc, const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long s = 0;
+    unsigned long long s = 0, wc = 0, ws = 0;
+    for (int b = 0; b < depth; ++b)
+        for (int k = 0; k < batch; ++k) {
+            wc += closestCounts[((size_t)b * rowStride + k) * kCtrStride];
+            ws += shadowCounts[((size_t)b * rowStride + k) * kCtrStride];
+        }
+    dc->workItems[0] += wc;
+    dc->workItems[1] += ws;
     for (int k = 0; k < batch; ++k) {
         Queues q = q0.at(k);
         for (int b = 0; b < depth; ++b) {
@@ -705,15 +714,26 @@ static inline int persistentGridX(int batch)
     int x = (1024 + batch - 1) / batch;
     return x < 1 ? 1 : x;
 }
-void ptl_intersect(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-                   uint32_t* fetchCtr, uint32_t* workCount, void* dc)
+/* intersect stage = cull (work list of the traversal) + trace (BVH meshes) + prims (everything else, hit record, sort bucket) */
+void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount)
 {
-    if (S.numBvhMeshes > 0) {
-        hipLaunchKernelGGL(k_cull, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, workCount);
-        dim3 grid(persistentGridX(bt.count), bt.count);
-        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)workCount, (DevCounters*)dc);
-        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, (const uint32_t*)workCount, (DevCounters*)dc);
+    hipLaunchKernelGGL(k_cull, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, workCount);
+}
+void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
+               uint32_t* fetchCtr, const uint32_t* workCount, void* dc)
+{
+    dim3 grid(persistentGridX(bt.count), bt.count);
+    DevCounters* d = (DevCounters*)dc;
+    if (shadow) {
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
+        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
+    } else {
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
+        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
     }
+}
+void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc)
+{
     if (count) hipLaunchKernelGGL(k_prims<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
     else hipLaunchKernelGGL(k_prims<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
 }
@@ -723,15 +743,10 @@ void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
     hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, numBuckets);
 }
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-               uint32_t* shadowFetchCtr, uint32_t* shadowCount, void* dc)
+               uint32_t* shadowCount, void* dc)
 {
     if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, (DevCounters*)dc);
     else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, (DevCounters*)dc);
-    if (S.numBvhMeshes > 0) {
-        dim3 grid(persistentGridX(bt.count), bt.count);
-        if (count) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, shadowFetchCtr, (const uint32_t*)shadowCount, (DevCounters*)dc);
-        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, shadowFetchCtr, (const uint32_t*)shadowCount, (DevCounters*)dc);
-    }
 }
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
 {
@@ -739,10 +754,11 @@ void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
     hipLaunchKernelGGL(k_compact_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, sortOn);
     if (!sortOn) hipLaunchKernelGGL(k_copy_queue, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce);
 }
-void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc)
+void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
+                const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride)
 {
     hipLaunchKernelGGL(k_final_gather, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, st, q, depth);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, bt.count, (DevCounters*)dc);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, bt.count, (DevCounters*)dc, shadowCounts, closestCounts, rowStride);
     const size_t n3 = 3 * st.numPixels;
     hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, bt.count);
 }
@@ -750,13 +766,13 @@ void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rg
 {
     hipLaunchKernelGGL(k_display, dim3(gridFor(n)), dim3(kBlock), 0, s, image, n, iter, rgba);
 }
-/* n <= st.numPixels rays through the production intersect stage (row 0 of the path state) */
-void ptl_intersect_rays(hipStream_t s, const SceneView& S, PathState st, Queues q, const float* o, const float* d, int n, PtHit* out,
-                        uint32_t* fetchCtr, uint32_t* workCount)
+/* stage-level hook: n <= st.numPixels caller rays into row 0 of the path state / hit records out */
+void ptl_import_rays(hipStream_t s, PathState st, Queues q, const float* o, const float* d, int n)
 {
     hipLaunchKernelGGL(k_import_rays, dim3(gridFor(n)), dim3(kBlock), 0, s, st, q, n, o, d);
-    Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
-    ptl_intersect(s, S, st, q, bt, 0, 0, false, fetchCtr, workCount, nullptr);
+}
+void ptl_export_hits(hipStream_t s, PathState st, int n, PtHit* out)
+{
     hipLaunchKernelGGL(k_export_hits, dim3(gridFor(n)), dim3(kBlock), 0, s, st, n, out);
 }
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d)

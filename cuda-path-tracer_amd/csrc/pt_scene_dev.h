@@ -128,13 +128,14 @@ struct Batch { int count; int iterBase; int iterStride; };
 
 struct DevCounters {
     unsigned long long pathBounces;
-    unsigned long long trav[2][3];      /* [0] intersect stage, [1] shade stage: nodes, triangles, mesh hits */
+    unsigned long long trav[2][4];      /* [0] intersect stage, [1] shade stage: nodes, triangles, mesh hits, child boxes */
+    unsigned long long workItems[2];    /* rays handed to the traversal kernel: closest-hit, shadow */
     unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
     unsigned long long waveDiag[2][6];  /* per traversal mode: wave iterations, node-step lanes, leaf-step lanes, held-leaf lanes, refills, refilled lanes */
     uint32_t lastLive[PT_MAX_DEPTH + 2];
 };
 
-struct TravCounters { uint32_t nodes, tris, meshHits; };
+struct TravCounters { uint32_t nodes, tris, meshHits, boxes; };
 
 constexpr float kPI = 3.1415926535897932384626422832795028841971f;
 constexpr float kTWO_PI = 6.2831853071795864769252867665590057683943f;
@@ -283,7 +284,11 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         const float4* q = S.nodes + 8 * ((size_t)tv.nodeStart + (size_t)ref);
         float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
         float4 rf = q[6];
-        if (COUNT) cnt.nodes++;
+        if (COUNT) {
+            cnt.nodes++;
+            cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
+                         (__float_as_int(rf.z) != kEmptyRef) + (__float_as_int(rf.w) != kEmptyRef);
+        }
         float tk[4];
         int rk[4];
         const F3 lo = tv.lo, invDir = tv.invDir;

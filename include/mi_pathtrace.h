@@ -185,6 +185,15 @@ typedef struct PtStats {
     uint64_t shadeNodesVisited;  /* the shade stage's share of the three traversal     */
     uint64_t shadeTrisTested;    /* counters above (shadow rays); the rest belongs to  */
     uint64_t shadeMeshHits;      /* the intersect stage                                */
+    /* the BVH traversal kernel on its own, in its two modes (the dominant kernels) */
+    float msTrace;               /* closest-hit traversal, HIP-event time (timing on)  */
+    float msShadowTrace;         /* shadow-ray traversal                               */
+    uint32_t launchesTrace;
+    uint32_t launchesShadowTrace;
+    uint64_t tracedRays;         /* rays handed to the closest-hit traversal (always)  */
+    uint64_t shadowRays;         /* shadow rays handed to the traversal (always)       */
+    uint64_t boxesTested;        /* child boxes slab-tested, both modes (counters on)  */
+    uint64_t shadeBoxesTested;   /* the shadow mode's share                            */
 } PtStats;
 
 /* Closest-hit record for the fixed-ray-set parity hook. */
@@ -204,7 +213,7 @@ enum PtOption {
     PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
     PT_OPT_USE_GRAPH = 5,        /* replay the iteration from a hipGraph (default 0)*/
     PT_OPT_BATCH = 6             /* iterations that share one launch group in
-                                    pt_trace_range (default 16, at most 64); results
+                                    pt_trace_range (default 16, at most 256); results
                                     do not depend on it                              */
 };
 

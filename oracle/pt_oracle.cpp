@@ -1522,6 +1522,7 @@ void oracle_trace(Oracle* o, int iter)
     o->stats.iterations++;
     o->stats.nodesVisited += cn + sn; o->stats.trisTested += ct + stt; o->stats.meshHits += ch + sh;
     o->stats.shadeNodesVisited += sn; o->stats.shadeTrisTested += stt; o->stats.shadeMeshHits += sh;
+    o->stats.boxesTested += cn + sn; o->stats.shadeBoxesTested += sn;      /* one box per binary node visit */
 }
 
 void oracle_image(Oracle* o, float* rgb)

@@ -25,7 +25,7 @@ def main():
     db = sqlite3.connect(a.db)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
-    sel = "name, (end - start)" + (", %s" % gcol if (a.grid and gcol) else "")
+    sel = "name, (end - start)" + (", 'grid ' || %s || 'x' || grid_y" % gcol if (a.grid and gcol) else "")
     rows = {}
     for r in db.execute("select %s from kernels" % sel):
         key = (short(r[0]),) + tuple(r[2:])
