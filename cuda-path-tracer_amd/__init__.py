@@ -146,6 +146,9 @@ def _load():
         "pt_scene_add_texture": (ip, [vp, vp, ip, ip, ip]),
         "pt_scene_set_envmap": (ip, [vp, vp, ip, ip, fp]),
         "pt_scene_free": (None, [vp]),
+        "pt_scene_image": (C.POINTER(C.c_float), [vp]),
+        "pt_scene_iterations": (C.c_int, [vp]),
+        "pt_scene_image_name": (C.c_char_p, [vp]),
         "pt_build_transforms": (None, [C.POINTER(fp)] * 6),
     }
     for name, (res, args) in sig.items():

@@ -62,6 +62,7 @@ struct PtScene {
     float fovy = 45.0f;
     int traceDepth = 8, iterations = 1;
     std::string imageName;
+    std::vector<float> image;           /* W*H*3 running sum on the host, filled by the pathtrace() shim */
     PtSceneDesc desc{};
 
     void refresh()
@@ -449,5 +450,15 @@ int pt_scene_set_envmap(PtScene* s, const float* rgb, int w, int h, float intens
 }
 
 void pt_scene_free(PtScene* s) { delete s; }
+
+float* pt_scene_image(PtScene* s)
+{
+    if (!s) return nullptr;
+    const size_t n = (size_t)s->cam.resolution[0] * s->cam.resolution[1] * 3;
+    if (s->image.size() != n) s->image.assign(n, 0.0f);
+    return s->image.data();
+}
+int pt_scene_iterations(const PtScene* s) { return s ? s->iterations : 0; }
+const char* pt_scene_image_name(const PtScene* s) { return s ? s->imageName.c_str() : ""; }
 
 } // extern "C"

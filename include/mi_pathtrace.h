@@ -304,6 +304,12 @@ int pt_scene_add_material(PtScene* s, const PtMaterial* m);
 int pt_scene_add_texture(PtScene* s, const uint8_t* data, int w, int h, int comps);
 int pt_scene_set_envmap(PtScene* s, const float* rgb, int w, int h, float intensity);
 void pt_scene_free(PtScene* s);
+/* Host image of the scene, W*H*3 floats (role of RenderState::image, src/sceneStructs.h:160-166, which
+ * pathtrace() refreshes with the running sum after every iteration, src/pathtrace.cu:2913-2917),
+ * plus the ITERATIONS and FILE entries of the camera block (src/scene.cpp:868-905). */
+float* pt_scene_image(PtScene* s);
+int pt_scene_iterations(const PtScene* s);
+const char* pt_scene_image_name(const PtScene* s);
 
 /* utilityCore::buildTransformationMatrix + glm::inverse + glm::inverseTranspose
  * (src/utilities.cpp:85-93, src/scene.cpp:848-851) for one TRS triple. */

@@ -8,6 +8,8 @@ Bars:
   * accumulated radiance vs the oracle's libm mode (the arithmetic a host build of the
     reference performs): per-channel RMSE <= RMSE_TOL of the mean radiance after SPP samples
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -310,3 +312,32 @@ def test_errors_are_reported(pt, scenes, gpu_ok):
     with pytest.raises(pt.PtError):
         pt.Tracer(sc)
     assert pt.lib.pt_destroy(None) == 0          # pathtraceFree before the first init is a no-op
+
+
+@pytest.mark.gpu
+def test_pathtrace_surface_headless_driver(pt, scenes, orc, gpu_ok, tmp_path):
+    """pathtraceInit / pathtrace(nullptr, 0, iter) / pathtraceFree driven the way runCuda drives them
+    (src/main.cpp:812-837), through the headless executable: the averaged image equals the oracle's, bit for bit,
+    one iteration per call as well as batched."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pt.LIB_PATH), "pt_headless")
+    path = scenes.write_scene_json("cornell", str(tmp_path))
+    W, H, n = 48, 40, 3
+    sc = pt.Scene(path)
+    sc.set_resolution(W, H)
+    sc.set_depth(6)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    for it in range(1, n + 1):
+        o.trace(it)
+    expect = (o.image().reshape(H, W, 3) * (np.float32(1.0) / np.float32(n))).astype(np.float32)
+    o.close()
+    for extra in ([], ["--batch"]):
+        out = str(tmp_path / ("img%d.pfm" % len(extra)))
+        subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", out] + extra, timeout=120)
+        with open(out, "rb") as f:
+            assert f.readline().strip() == b"PF"
+            w, h = map(int, f.readline().split())
+            assert (w, h) == (W, H) and float(f.readline()) < 0
+            got = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
+        assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
+        assert got.sum() > 0

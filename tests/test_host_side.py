@@ -26,10 +26,30 @@ def test_library_exports_every_declared_symbol(pt):
     assert b"gfx950" in pt.lib.pt_version()
 
 
+def test_library_exports_the_pathtrace_surface(pt):
+    """pathtraceInit / pathtrace / pathtraceFree / InitDataContainer (src/pathtrace.h:8-11) as C++ symbols."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", pt.LIB_PATH], text=True)
+    for sig in ("pathtraceInit(PtScene*)", "pathtraceFree()", "pathtrace(uchar4*, int, int)", "InitDataContainer(GuiDataContainer*)"):
+        assert sig in out, sig
+    headless = os.path.join(os.path.dirname(pt.LIB_PATH), "pt_headless")
+    assert os.access(headless, os.X_OK)
+
+
+def test_pod_sizes_match_the_reference_structs(pt):
+    """Material 124 B, Triangle 100 B, BVHNode 40 B, Camera 84 B (src/sceneStructs.h:40-194, src/bvh.h:16-65,
+    sizes measured by compiling the reference headers): a binding can hand the reference's arrays over as they are."""
+    assert C.sizeof(pt.PtMaterial) == 124
+    assert pt.TRI_DTYPE.itemsize == 100
+    assert pt.NODE_DTYPE.itemsize == 40
+    assert C.sizeof(pt.PtCamera) == 84
+    assert pt.HIT_DTYPE.itemsize == 36
+
+
 def test_library_holds_gfx950_code_object(pt):
     blob = open(pt.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
-    for kernel in (b"k_intersect", b"k_shade", b"k_sort_scatter", b"k_compact_scatter", b"k_camera"):
+    for kernel in (b"k_trace", b"k_prims", b"k_cull", b"k_shade", b"k_sort_scatter", b"k_compact_scatter", b"k_camera"):
         assert kernel in blob
 
 
