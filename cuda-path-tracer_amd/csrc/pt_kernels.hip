@@ -19,6 +19,8 @@
  */
 #include "pt_scene_dev.h"
 
+#include <cstdlib>
+
 namespace ptd {
 
 PT_DEV int laneId() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -710,8 +712,9 @@ void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathSta
 }
 static inline int persistentGridX(int batch)
 {
+    static const int total = [] { const char* e = getenv("PT_PERSIST_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     /* 256 CUs x 4 workgroups of 4 waves = 16 waves per CU in flight; split over the batch rows */
-    int x = (1024 + batch - 1) / batch;
+    int x = (total + batch - 1) / batch;
     return x < 1 ? 1 : x;
 }
 /* intersect stage = cull (work list of the traversal) + trace (BVH meshes) + prims (everything else, hit record, sort bucket) */
