@@ -191,6 +191,51 @@ def test_iterations_bit_exact_mesh_textures_env(pt, scenes, orc, gpu_ok):
     _assert_full_parity(pt, orc, sc, [1, 2])
 
 
+def _three_mesh_scene(pt, scenes, res):
+    """cornell_orig + three overlapping BVH meshes (two blobs that intersect each other and a cube sunk into both):
+    closest hits and shadow rays have to be folded across meshes."""
+    sc = scenes.make_scene("cornell_orig", res=res, depth=8)
+    ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    m0 = sc.add_material(type=pt.PT_PBR, color=[0.9, 0.6, 0.3], roughness=0.4, metallic=0.0, indexOfRefraction=1.5)
+    m1 = sc.add_material(type=pt.PT_PBR, color=[0.95, 0.8, 0.6], roughness=0.05, metallic=0.0, transparency=0.9, indexOfRefraction=1.5)
+    m2 = sc.add_material(type=pt.PT_PBR, color=[0.7, 0.7, 0.9], roughness=0.3, metallic=1.0, indexOfRefraction=1.5)
+    sc.add_mesh(scenes.blob_mesh(24, 25, 11, ident, [m0, m1], radius=2.2, center=(-1.0, 4.0, 0.0)))
+    sc.add_mesh(scenes.cube_mesh(((0.2, 6.4, 0.3), (0.0, 0.0, 0.0), (1.5, 1.5, 1.5)), m2))
+    sc.add_mesh(scenes.blob_mesh(20, 21, 12, ident, [m2, m0], radius=2.0, center=(1.2, 4.5, 0.4)))
+    return sc
+
+
+def test_several_bvh_meshes_bit_exact(pt, scenes, orc, gpu_ok):
+    sc = _three_mesh_scene(pt, scenes, (72, 72))
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    ro, rd = _ray_set(5, 30000, center=(0.0, 4.0, 0.0), radius=9.0)
+    g, ob = tr.intersect(ro, rd), o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    geoms_hit = set(np.unique(g["geom"][g["triangle"] >= 0]).tolist())
+    assert len(geoms_hit) == 3, geoms_hit
+    _assert_full_parity(pt, orc, sc, [1, 2, 3])
+
+
+def test_use_bvh_off_iterations_bit_exact(pt, scenes, orc, gpu_ok):
+    """USE_BVH 0 (src/pathtrace.cu:193): meshes are scanned linearly, in the closest-hit stage and in shadow rays."""
+    sc = _three_mesh_scene(pt, scenes, (40, 40))
+    tr = pt.Tracer(sc)
+    tr.set_option(pt.PT_OPT_USE_BVH, 0)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    o.set_option(pt.PT_OPT_USE_BVH, 0)
+    for it in (1, 2):
+        tr.trace(it)
+        o.trace(it)
+    assert tr.stats().pathBounces == o.stats().pathBounces
+    assert _same_bits(tr.image(), o.image())
+    # and it is the same picture as with the BVH on
+    tr2 = pt.Tracer(sc)
+    for it in (1, 2):
+        tr2.trace(it)
+    assert _same_bits(tr.image(), tr2.image())
+
+
 def test_material_sort_off_bit_exact(pt, scenes, orc, gpu_ok):
     """MATERIAL_SORTING 0 (src/pathtrace.h:6): slots keep compacted order, so RNG streams differ from sort-on."""
     sc = scenes.make_scene("cornell", res=(96, 96), depth=8)
