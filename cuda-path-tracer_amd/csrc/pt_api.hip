@@ -224,6 +224,98 @@ void pushTriangle(FlatMesh& fm, const PtTriangle& t, int orig)
     fm.cold.push_back(make_float4(t.uv1[1], t.uv2[0], t.uv2[1], asF(t.materialId)));
 }
 
+/* The hierarchy ABOVE the leaves is free: a traversal result depends on the reference's leaves and their
+ * boxes only (which triangles get tested, and their visit ranks).  UpperTree rebuilds it over the leaves of
+ * the host BVH, top-down with a binned surface-area heuristic on the leaf boxes (32 bins per axis, all three
+ * axes, cost = area x triangles), median split on the widest axis when binning cannot separate or the tree
+ * gets deep, and emits 4-wide nodes by opening, per node, the child with the largest box. */
+struct UpperTree {
+    struct Leaf { float lo[3], hi[3], cen[3]; int first, count; };
+    struct Node { float lo[3], hi[3]; int left, right, leaf; };   /* leaf >= 0: index into leaves */
+    std::vector<Leaf> leaves;
+    std::vector<int> order;
+    std::vector<Node> nodes;
+    static constexpr int kBins = 32;
+
+    static float halfArea(const float* lo, const float* hi)
+    {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static void grow(float* lo, float* hi, const float* l2, const float* h2)
+    {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l2[k]); hi[k] = std::max(hi[k], h2[k]); }
+    }
+    int build(int first, int last, int depth)
+    {
+        const int id = (int)nodes.size();
+        nodes.push_back(Node{});
+        float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        float clo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, chi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        for (int i = first; i < last; ++i) {
+            const Leaf& L = leaves[order[i]];
+            grow(lo, hi, L.lo, L.hi);
+            grow(clo, chi, L.cen, L.cen);
+        }
+        Node nd{};
+        memcpy(nd.lo, lo, 12); memcpy(nd.hi, hi, 12);
+        nd.left = nd.right = -1; nd.leaf = -1;
+        if (last - first == 1) { nd.leaf = order[first]; nodes[id] = nd; return id; }
+        int mid = -1;
+        if (depth < 28) {
+            float bestCost = 3.4e38f; int bestAxis = -1, bestBin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                const float ext = chi[axis] - clo[axis];
+                if (!(ext > 0.0f)) continue;
+                const float scale = kBins / ext;
+                float blo[kBins][3], bhi[kBins][3]; int bn[kBins];
+                for (int b = 0; b < kBins; ++b) { for (int k = 0; k < 3; ++k) { blo[b][k] = 3.4e38f; bhi[b][k] = -3.4e38f; } bn[b] = 0; }
+                for (int i = first; i < last; ++i) {
+                    const Leaf& L = leaves[order[i]];
+                    int b = std::min(kBins - 1, std::max(0, (int)((L.cen[axis] - clo[axis]) * scale)));
+                    grow(blo[b], bhi[b], L.lo, L.hi);
+                    bn[b] += L.count;
+                }
+                float rlo[kBins][3], rhi[kBins][3]; int rn[kBins];
+                float alo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, ahi[3] = { -3.4e38f, -3.4e38f, -3.4e38f }; int an = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    if (bn[b]) grow(alo, ahi, blo[b], bhi[b]);
+                    an += bn[b];
+                    memcpy(rlo[b], alo, 12); memcpy(rhi[b], ahi, 12); rn[b] = an;
+                }
+                float llo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, lhi[3] = { -3.4e38f, -3.4e38f, -3.4e38f }; int ln = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    if (bn[b]) grow(llo, lhi, blo[b], bhi[b]);
+                    ln += bn[b];
+                    if (ln == 0 || rn[b + 1] == 0) continue;
+                    float cost = halfArea(llo, lhi) * ln + halfArea(rlo[b + 1], rhi[b + 1]) * rn[b + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+                }
+            }
+            if (bestAxis >= 0) {
+                const float scale = kBins / (chi[bestAxis] - clo[bestAxis]);
+                auto it = std::partition(order.begin() + first, order.begin() + last, [&](int li) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((leaves[li].cen[bestAxis] - clo[bestAxis]) * scale)));
+                    return b <= bestBin;
+                });
+                mid = (int)(it - order.begin());
+            }
+        }
+        if (mid <= first || mid >= last) {
+            int axis = 0;
+            for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+            mid = (first + last) / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + last,
+                             [&](int a, int b) { return leaves[a].cen[axis] < leaves[b].cen[axis]; });
+        }
+        int l = build(first, mid, depth + 1);
+        int r = build(mid, last, depth + 1);
+        nd.left = l; nd.right = r;
+        nodes[id] = nd;
+        return id;
+    }
+};
+
 /* Turns the host BVH (40-byte binary nodes + index array, src/bvh.h:55-65) into the device
  * layout: triangles permuted into leaf order, each stamped with its rank in the reference's
  * visit order (right subtree first, src/intersections.cu:379-384), and the inner levels
@@ -330,6 +422,42 @@ struct Flattener {
         }
         return id;
     }
+    /* same collapse over a rebuilt upper tree */
+    int collapseUpper(const UpperTree& U, int i, int depth)
+    {
+        int id = newNode4();
+        fm.depth4 = std::max(fm.depth4, depth + 1);
+        int kids[4] = { U.nodes[i].left, U.nodes[i].right, -1, -1 };
+        int nk = 2;
+        while (nk < 4) {
+            int pick = -1;
+            float bestA = -1.0f;
+            for (int k = 0; k < nk; ++k) {
+                const UpperTree::Node& c = U.nodes[kids[k]];
+                float a = UpperTree::halfArea(c.lo, c.hi);
+                if (c.leaf < 0 && a > bestA) { bestA = a; pick = k; }
+            }
+            if (pick < 0) break;
+            int c = kids[pick];
+            for (int k = nk; k > pick + 1; --k) kids[k] = kids[k - 1];
+            kids[pick] = U.nodes[c].left;
+            kids[pick + 1] = U.nodes[c].right;
+            ++nk;
+        }
+        for (int k = 0; k < nk; ++k) {
+            const UpperTree::Node& c = U.nodes[kids[k]];
+            int ref;
+            if (c.leaf >= 0) {
+                const UpperTree::Leaf& L = U.leaves[c.leaf];
+                ref = leafRef(L.first, L.count, L.lo, L.hi, depth + 1);
+                setChild(id, k, L.lo, L.hi, ref);
+            } else {
+                ref = collapseUpper(U, kids[k], depth + 1);
+                setChild(id, k, c.lo, c.hi, ref);
+            }
+        }
+        return id;
+    }
     /* inner source node -> 4-wide node: open the child with the largest box until four slots are used */
     int collapse(int i, int depth)
     {
@@ -379,7 +507,29 @@ int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nn
         fm.depth4 = 1;
         F.setChild(id, 0, nodes[0].bmin, nodes[0].bmax, F.leafRef(F.leafFirst[0], nodes[0].triangleCount, nodes[0].bmin, nodes[0].bmax, 1));
     } else {
-        F.collapse(0, 0);
+        static const bool rebuildUpper = [] { const char* e = getenv("PT_UPPER_TREE"); return !e || atoi(e) != 0; }();
+        bool done = false;
+        if (rebuildUpper) {
+            UpperTree U;
+            for (int i = 0; i < nnodes; ++i) {
+                if (!F.seen[i] || nodes[i].leftChild != -1) continue;
+                UpperTree::Leaf L;
+                memcpy(L.lo, nodes[i].bmin, 12); memcpy(L.hi, nodes[i].bmax, 12);
+                for (int k = 0; k < 3; ++k) L.cen[k] = 0.5f * (L.lo[k] + L.hi[k]);
+                L.first = F.leafFirst[i]; L.count = nodes[i].triangleCount;
+                U.leaves.push_back(L);
+            }
+            U.order.resize(U.leaves.size());
+            for (size_t i = 0; i < U.order.size(); ++i) U.order[i] = (int)i;
+            U.nodes.reserve(2 * U.leaves.size());
+            if (U.leaves.size() >= 2) {
+                int root = U.build(0, (int)U.leaves.size(), 0);
+                F.collapseUpper(U, root, 0);
+                done = 3 * fm.depth4 + 1 <= kLdsStack + kOverflowStack;
+                if (!done) { fm.nodes.clear(); fm.depth4 = 0; }      /* too deep: fall back to the host topology */
+            }
+        }
+        if (!done) F.collapse(0, 0);
     }
     /* every visit pushes at most three entries */
     if (3 * fm.depth4 + 1 > kLdsStack + kOverflowStack) {
