@@ -4,10 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one iteration of the wavefront loop (one sample per pixel) on every rank.  Ranks render
-disjoint, interleaved iteration indices of the same replicated scene (iterations are independent given
-the iteration index, which seeds every RNG stream); after the timed steps the per-rank running sums are
-summed with one all-reduce over RCCL.  value = path-bounces of all ranks / time (path-bounce = one live
+A step is one launch group of the wavefront loop on every rank: --spp-per-step iterations (one sample per
+pixel each, default 64) that share every kernel launch.  Ranks render disjoint, interleaved iteration
+indices of the same replicated scene (iterations are independent given the iteration index, which seeds
+every RNG stream); after the timed steps the per-rank running sums are summed with one all-reduce over
+RCCL.  value = path-bounces of all ranks / time (path-bounce = one live
 path entering the intersect stage for one bounce).
 
 Prints ONE JSON line on rank 0.
@@ -41,13 +42,13 @@ VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CUs x 128 lanes x 2 flop 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=64, help="iterations sharing one launch group = one step (1..256)")
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sort", action="store_true", help="MATERIAL_SORTING 0")
-    ap.add_argument("--cpu-spp", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="iterations sharing one launch group (0 = min(steps, 64))")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: whole iterations until this much time has passed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,19 +86,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...
-        return 1 + rank + step * world
+    B = max(1, min(args.spp_per_step, 256))
+
+    def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...; B of them per step
+        return 1 + rank + step * B * world
 
     # ---- untimed: warmup, then a counted pass over the timed iterations (exact node / triangle counts)
-    batch = args.batch if args.batch else max(1, min(args.steps, 64))
-    tr.set_option(pt.PT_OPT_BATCH, batch)
+    tr.set_option(pt.PT_OPT_BATCH, B)
     if args.warmup:
         tr.trace_range(it_index(0), it_index(args.warmup), world)
     barrier()
     tr.reset_stats()
     tr.clear()
     tr.set_option(pt.PT_OPT_COUNTERS, 1)
-    count_steps = min(args.steps, 4)
+    count_steps = 1
     tr.trace_range(it_index(args.warmup), it_index(args.warmup + count_steps), world)
     cs = tr.stats()
     counted = dict(pb=cs.pathBounces, rays=cs.tracedRays, shadow_rays=cs.shadowRays,
@@ -167,7 +169,7 @@ def main():
                     "valu_frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                     "loop_alg_bytes_per_path_bounce": round(b_loop, 1),
                     "loop_alg_gbs": round(b_loop * total_pb / world / elapsed / 1e9, 1),
-                    "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stages.items()}}
+                    "stage_ms_per_spp": {k: round(v / (args.steps * B), 4) for k, v in stages.items()}}
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -175,23 +177,26 @@ def main():
             import oracle_binding as orc                    # the checker, timed as the CPU baseline only
             o = orc.Oracle(pt, sc, orc.MATH_LIBM)
             c0 = time.perf_counter()
-            for it in range(1, args.cpu_spp + 1):
-                o.trace(it)
+            cpu_spp = 0
+            while cpu_spp < 1 or (time.perf_counter() - c0 < args.cpu_seconds and cpu_spp < 4096):
+                cpu_spp += 1
+                o.trace(cpu_spp)
             c1 = time.perf_counter()
             os_ = o.stats()
             cpu = {"value": round(os_.pathBounces / (c1 - c0) / 1e6, 4), "unit": "Mpaths*bounce/s", "cores": orc.threads(),
                    "kind": "port",
-                   "sample": "%d spp of the same workload (%d path-bounces, %.1f s) on the CPU restatement, OpenMP over queue slots"
-                             % (args.cpu_spp, os_.pathBounces, c1 - c0)}
+                   "sample": "%d spp of the same workload (%d path-bounces, %.1f s) on the CPU restatement of the reference's loop, "
+                             "OpenMP over queue slots, libm arithmetic" % (cpu_spp, os_.pathBounces, c1 - c0)}
             o.close()
 
         out = {"metric": "Mpaths*bounce/s (%s)" % scene_name, "value": round(value, 3), "unit": "Mpaths*bounce/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": desc, "resolution": list(res), "depth": depth, "spp_per_step_per_gpu": 1,
-                          "material_sort": not args.no_sort, "iterations_per_launch_group": batch, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
-                          "path_bounces_per_spp": round(st.pathBounces / max(args.steps, 1), 1)},
+               "config": {"workload": desc, "resolution": list(res), "depth": depth, "spp_per_step_per_gpu": B,
+                          "ms_per_spp": round(elapsed / (args.steps * B) * 1e3, 5),
+                          "material_sort": not args.no_sort, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
+                          "path_bounces_per_spp": round(st.pathBounces / max(args.steps * B, 1), 1)},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int t
 #define PT_SHADE_MINWAVES 4
 #endif
 #ifndef PT_LEAF_WAIT
-#define PT_LEAF_WAIT 16
+#define PT_LEAF_WAIT 24
 #endif
 constexpr int kRefillThreshold = PT_REFILL;
 constexpr int kLeafWait = PT_LEAF_WAIT;

@@ -6,5 +6,5 @@ for w in cornell sss dragon chess halo; do
     python3 -c "
 import json
 d = json.loads(open('gpurun_out/bench_$w.json').read().strip().splitlines()[-1])
-print(d['value'], 'Mpb/s', d['ms_per_step'], 'ms/spp', d['roofline']['stage_ms_per_step'])" || exit 1
+print(d['value'], 'Mpb/s', d['ms_per_step'], 'ms/spp', d['config']['ms_per_spp'], d['roofline']['stage_ms_per_spp'])" || exit 1
 done

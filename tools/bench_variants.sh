@@ -10,5 +10,5 @@ for v in "$@"; do
     python3 -c "
 import json
 d = json.loads(open('/tmp/bv.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['stage_ms_per_step'])" || exit 1
+print(d['value'], d['ms_per_step'], d['config']['ms_per_spp'], d['roofline']['stage_ms_per_spp'])" || exit 1
 done
