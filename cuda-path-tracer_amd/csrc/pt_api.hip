@@ -46,8 +46,10 @@ void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, floa
         }                                                                                          \
     } while (0)
 
+constexpr int kDefaultStreamGroups = 2;
 constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
 constexpr int kMaxBatch = 256;
+constexpr int kMaxStreamGroups = 8;
 /* device work counters, zeroed before every launch group: [section][bounce][batch row] with sections
  * 0 = next entry of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length,
  * 3 = closest-hit work queue length */
@@ -67,6 +69,9 @@ struct PtContext {
     DevCounters* dc = nullptr;
     uint32_t* workCtr = nullptr;
     int bvhMeshGeoms = 0;               /* mesh geoms that own a BVH */
+    int streamGroups = 1;               /* streams the rows of a launch group are spread over */
+    hipStream_t groupStreams[kMaxStreamGroups] = {};
+    hipEvent_t forkEvent = nullptr, joinEvents[kMaxStreamGroups] = {};
     PtCamera cam{};
     int traceDepth = 8;
     int numPixels = 0;
@@ -549,15 +554,15 @@ hipEvent_t takeEvent(PtContext* c)
 }
 
 struct SpanGuard {
-    PtContext* c; int stage; hipEvent_t a = nullptr;
-    SpanGuard(PtContext* ctx, int st) : c(ctx), stage(st)
+    PtContext* c; int stage; hipStream_t stream; hipEvent_t a = nullptr;
+    SpanGuard(PtContext* ctx, int st, hipStream_t s = nullptr) : c(ctx), stage(st), stream(s ? s : ctx->stream)
     {
         c->launches[stage]++;
-        if (c->timing) { a = takeEvent(c); (void)hipEventRecord(a, c->stream); }
+        if (c->timing) { a = takeEvent(c); (void)hipEventRecord(a, stream); }
     }
     ~SpanGuard()
     {
-        if (c->timing) { hipEvent_t b = takeEvent(c); (void)hipEventRecord(b, c->stream); c->spans.push_back({ a, b, stage }); }
+        if (c->timing) { hipEvent_t b = takeEvent(c); (void)hipEventRecord(b, stream); c->spans.push_back({ a, b, stage }); }
     }
 };
 
@@ -585,6 +590,11 @@ int pt_destroy(PtContext* c)
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->batchAllocs) (void)hipFree(p);
+    for (int g = 0; g < kMaxStreamGroups; ++g) {
+        if (c->groupStreams[g]) (void)hipStreamDestroy(c->groupStreams[g]);
+        if (c->joinEvents[g]) (void)hipEventDestroy(c->joinEvents[g]);
+    }
+    if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -627,6 +637,12 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
 #define TRY_RC(x) do { rc = (x); if (rc != PT_OK) { pt_destroy(c); return rc; } } while (0)
 #define TRY_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { pt_set_error("%s failed: %s", #x, hipGetErrorString(e_)); pt_destroy(c); return PT_EHIP; } } while (0)
     TRY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TRY_HIP(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
+    for (int g = 0; g < kMaxStreamGroups; ++g) {
+        TRY_HIP(hipStreamCreateWithFlags(&c->groupStreams[g], hipStreamNonBlocking));
+        TRY_HIP(hipEventCreateWithFlags(&c->joinEvents[g], hipEventDisableTiming));
+    }
+    { const char* e = getenv("PT_STREAMS"); int v = e ? atoi(e) : kDefaultStreamGroups; c->streamGroups = std::max(1, std::min(v, kMaxStreamGroups)); }
 
     /* ---- meshes: concatenated in geom order (src/pathtrace.cu:483-505), one BVH per mesh (:269-334) */
     std::vector<DGeom> geoms(d->geomCount);
@@ -774,33 +790,52 @@ static int traceBatch(PtContext* c, Batch bt)
     const bool count = c->counters != 0;
     uint32_t* ctr = c->workCtr;
     HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
-    { SpanGuard g(c, ST_CAMERA); ptl_camera(s, c->cam, bt, c->traceDepth, c->state, c->queues); }
     uint32_t* closestFetch = ctr;
     uint32_t* shadowFetch = ctr + kWorkCtrSection;
     uint32_t* shadowCount = ctr + 2 * kWorkCtrSection;
     uint32_t* closestCount = ctr + 3 * kWorkCtrSection;
     const bool meshes = V.numBvhMeshes > 0;
-    for (int b = 0; b < c->traceDepth; ++b) {
-        const size_t row = (size_t)b * kMaxBatch * kCtrStride;
-        {
-            SpanGuard g(c, ST_INTERSECT);
-            if (meshes) {
-                ptl_cull(s, V, c->state, c->queues, bt, b, closestCount + row);
-                SpanGuard t(c, ST_TRACE);
-                ptl_trace(s, V, c->state, c->queues, bt, b, false, count, closestFetch + row, closestCount + row, c->dc);
+    /* The rows of a launch group are independent until the final accumulation, so they can be spread over
+     * several streams: while one group's traversal kernel drains its last long rays, the kernels of the
+     * other groups fill the machine.  With stage timing on everything stays on one stream so that the
+     * event-bracketed durations are those of kernels running alone. */
+    const int groups = (c->timing || bt.count < 2 * c->streamGroups) ? 1 : c->streamGroups;
+    if (groups > 1) HIP_TRY(hipEventRecord(c->forkEvent, s));
+    for (int g = 0; g < groups; ++g) {
+        const int r0 = (int)((long long)bt.count * g / groups), r1 = (int)((long long)bt.count * (g + 1) / groups);
+        hipStream_t gs = groups > 1 ? c->groupStreams[g] : s;
+        if (groups > 1) HIP_TRY(hipStreamWaitEvent(gs, c->forkEvent, 0));
+        Batch gb; gb.count = r1 - r0; gb.iterBase = bt.iterBase + r0 * bt.iterStride; gb.iterStride = bt.iterStride;
+        PathState st = c->state.at(r0);
+        Queues q = c->queues.at(r0);
+        const size_t rowOff = (size_t)r0 * kCtrStride;
+        { SpanGuard sg(c, ST_CAMERA, gs); ptl_camera(gs, c->cam, gb, c->traceDepth, st, q); }
+        for (int b = 0; b < c->traceDepth; ++b) {
+            const size_t row = (size_t)b * kMaxBatch * kCtrStride + rowOff;
+            {
+                SpanGuard sg(c, ST_INTERSECT, gs);
+                if (meshes) {
+                    ptl_cull(gs, V, st, q, gb, b, closestCount + row);
+                    SpanGuard t(c, ST_TRACE, gs);
+                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + row, closestCount + row, c->dc);
+                }
+                ptl_prims(gs, V, st, q, gb, b, c->sortOn, count, c->dc);
             }
-            ptl_prims(s, V, c->state, c->queues, bt, b, c->sortOn, count, c->dc);
-        }
-        if (c->sortOn) { SpanGuard g(c, ST_SORT); ptl_sort(s, c->queues, bt, b, V.numBuckets); }
-        {
-            SpanGuard g(c, ST_SHADE);
-            ptl_shade(s, V, c->state, c->queues, bt, b, c->sortOn, count, shadowCount + row, c->dc);
-            if (meshes) {
-                SpanGuard t(c, ST_SHADOW_TRACE);
-                ptl_trace(s, V, c->state, c->queues, bt, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
+            if (c->sortOn) { SpanGuard sg(c, ST_SORT, gs); ptl_sort(gs, q, gb, b, V.numBuckets); }
+            {
+                SpanGuard sg(c, ST_SHADE, gs);
+                ptl_shade(gs, V, st, q, gb, b, c->sortOn, count, shadowCount + row, c->dc);
+                if (meshes) {
+                    SpanGuard t(c, ST_SHADOW_TRACE, gs);
+                    ptl_trace(gs, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
+                }
             }
+            { SpanGuard sg(c, ST_COMPACT, gs); ptl_compact(gs, q, gb, b, c->sortOn); }
         }
-        { SpanGuard g(c, ST_COMPACT); ptl_compact(s, c->queues, bt, b, c->sortOn); }
+        if (groups > 1) {
+            HIP_TRY(hipEventRecord(c->joinEvents[g], gs));
+            HIP_TRY(hipStreamWaitEvent(s, c->joinEvents[g], 0));
+        }
     }
     ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc, shadowCount, closestCount, kMaxBatch);
     HIP_TRY(hipGetLastError());

@@ -92,7 +92,7 @@ struct PathState {
     int* workQueue;                 /* pixels the traversal kernel has to visit, in arrival order: rays that may hit a
                                        BVH mesh before shading, pending shadow rays after it */
     size_t numPixels;
-    PT_DEV PathState at(int k) const
+    __host__ PT_DEV PathState at(int k) const
     {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
@@ -112,7 +112,7 @@ struct Queues {
     int numBlocks;      /* ceil(N / kBlock)                                              */
     int numPixels;
     int numBuckets;
-    PT_DEV Queues at(int k) const
+    __host__ PT_DEV Queues at(int k) const
     {
         Queues r = *this;
         const size_t off = (size_t)k * numPixels;
