@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64, help="iterations sharing one launch group = one step (1..256)")
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (one GPU per rank); gloo only to rehearse several ranks on a box with fewer GPUs")
     ap.add_argument("--no-sort", action="store_true", help="MATERIAL_SORTING 0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: whole iterations until this much time has passed")
     args = ap.parse_args()
@@ -65,10 +67,15 @@ def main():
     pt = entry._load_package()
     scenes = importlib.import_module("cuda_path_tracer_amd.scenes")
 
+    if args.backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)       # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     scene_name, res, depth, desc = WORKLOADS[args.workload]
     sc = scenes.make_scene(scene_name, res=res, depth=depth)
@@ -189,6 +196,21 @@ def main():
                     "measured_in": "a second pass over the same %d steps with HIP events around every stage and the launch group on one "
                                    "stream (%.3f ms per spp; the timed region overlaps two half-groups on two streams)"
                                    % (args.steps, (p1 - p0) / (args.steps * B) * 1e3)}
+
+        if st.launchesTrace == 0:
+            # analytic scenes (no BVH mesh): the streaming kernels are all there is; the larger of the two stages is reported
+            # with its share of the 192 streaming bytes per path-bounce (intersect 84 = path read 48 + hit written 28 + key and
+            # index 8; shade 108 = path written 48 + hit read 28 + key and index read 8 + image 24)
+            dom, ms_dom, launches, b_pb = (("k_shade", st.msShade, st.launchesShade, 108.0) if st.msShade >= st.msIntersect
+                                           else ("k_prims", st.msIntersect, st.launchesIntersect, 84.0))
+            avg_ms = ms_dom / max(launches, 1)
+            units = st.pathBounces / max(launches, 1)
+            achieved = b_pb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "alg_bytes_per_path_bounce": b_pb, "path_bounces_per_launch": round(units, 1),
+                        "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                        "stage_ms_per_spp": roofline["stage_ms_per_spp"], "measured_in": roofline["measured_in"]}
 
         cpu = None
         if not args.no_cpu_baseline:
