@@ -359,8 +359,15 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         sp--;
         float t;
         int r2;
-        if (sp < kLdsStack) { r2 = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]); }
-        else { r2 = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack]; }
+        /* the empty asm statements keep the two address spaces apart: merged into one generic-pointer
+         * load, every pop would be a flat access that waits for all outstanding vector memory as well */
+        if (sp < kLdsStack) {
+            r2 = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]);
+            asm volatile("" : "+v"(r2), "+v"(t));
+        } else {
+            r2 = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack];
+            asm volatile("" : "+v"(r2), "+v"(t));
+        }
         if (!(t > tv.closestT)) { tv.sp = sp; tv.ref = r2; return true; }
     }
     tv.sp = 0;
