@@ -150,6 +150,7 @@ def _load():
         "pt_scene_iterations": (C.c_int, [vp]),
         "pt_scene_image_name": (C.c_char_p, [vp]),
         "pt_build_transforms": (None, [C.POINTER(fp)] * 6),
+        "pt_bvh_device_layout": (C.c_int, [vp, C.c_int, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
@@ -191,6 +192,24 @@ def bvh_build(tris, max_depth=24):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         lib.pt_bvh_stats(h, C.byref(a), C.byref(b), C.byref(c))
         return nodes, idx, {"nodes": a.value, "leaves": b.value, "max_depth": c.value}
+    finally:
+        lib.pt_bvh_free(h)
+
+
+class PtLayoutStats(C.Structure):
+    _fields_ = [("wideNodes", C.c_int32), ("wideDepth", C.c_int32), ("leaves", C.c_int32), ("trianglesReferenced", C.c_int32),
+                ("sahCostHost", C.c_float), ("sahCostDevice", C.c_float)]
+
+
+def bvh_device_layout(tris, max_depth=24):
+    """Build the host BVH, derive the device layout from it on the CPU and validate it (pt_bvh_device_layout)."""
+    tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+    h = C.c_void_p()
+    _check(lib.pt_bvh_build(tris.ctypes.data, len(tris), max_depth, C.byref(h)), "pt_bvh_build")
+    try:
+        st = PtLayoutStats()
+        _check(lib.pt_bvh_device_layout(tris.ctypes.data, len(tris), h, C.byref(st)), "pt_bvh_device_layout")
+        return st
     finally:
         lib.pt_bvh_free(h)
 

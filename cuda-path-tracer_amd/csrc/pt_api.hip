@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <vector>
 
@@ -580,6 +581,80 @@ void resolveSpans(PtContext* c)
 } // namespace
 
 extern "C" {
+
+int pt_bvh_device_layout(const PtTriangle* triangles, int triangleCount, const PtBvh* bvh, PtLayoutStats* out)
+{
+    if (!triangles || triangleCount <= 0 || !bvh || !out) { pt_set_error("pt_bvh_device_layout: bad argument"); return PT_EINVAL; }
+    int nn = 0, ni = 0;
+    const PtBvhNode* nodes = pt_bvh_nodes(bvh, &nn);
+    const int32_t* idx = pt_bvh_indices(bvh, &ni);
+    FlatMesh fm;
+    int rc = flattenMesh(triangles, triangleCount, nodes, nn, idx, ni, fm);
+    if (rc != PT_OK) return rc;
+    memset(out, 0, sizeof(*out));
+    const int ntri = (int)(fm.hot.size() / 3);
+    std::vector<int> refs(ntri, 0);
+    auto halfArea = [](const float* lo, const float* hi) { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return dx * dy + dy * dz + dz * dx; };
+    /* walk the 4-wide hierarchy; returns the box of everything below `ref` measured on the triangles themselves */
+    struct Box { float lo[3], hi[3]; };
+    const float rootArea = halfArea(nodes[0].bmin, nodes[0].bmax);
+    double cost = 0.0;
+    int maxDepth = 0;
+    bool ok = true;
+    std::function<Box(int, int)> walk = [&](int ref, int depth) -> Box {
+        Box b; for (int k = 0; k < 3; ++k) { b.lo[k] = 3.4e38f; b.hi[k] = -3.4e38f; }
+        if (ref < 0) {
+            unsigned x = ~(unsigned)ref;
+            int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
+            out->leaves++;
+            for (int i = first; i < first + count && i < ntri; ++i) {
+                refs[i]++;
+                const float4* h = &fm.hot[3 * (size_t)i];
+                float v0[3] = { h[0].x, h[0].y, h[0].z }, e1[3] = { h[0].w, h[1].x, h[1].y }, e2[3] = { h[1].z, h[1].w, h[2].x };
+                for (int k = 0; k < 3; ++k) {
+                    /* the vertices as the host BVH saw them: v0 and v0 + edge can differ from v1, v2 by one rounding */
+                    float a = v0[k], c1 = v0[k] + e1[k], c2 = v0[k] + e2[k];
+                    b.lo[k] = std::min(b.lo[k], std::min(a, std::min(c1, c2)));
+                    b.hi[k] = std::max(b.hi[k], std::max(a, std::max(c1, c2)));
+                }
+            }
+            return b;
+        }
+        maxDepth = std::max(maxDepth, depth + 1);
+        out->wideNodes++;
+        const float4* q = &fm.nodes[8 * (size_t)ref];
+        for (int s = 0; s < 4; ++s) {
+            int cr; float f = (&q[6].x)[s]; memcpy(&cr, &f, 4);
+            if (cr == kEmptyRef) continue;
+            float lo[3] = { (&q[0].x)[s], (&q[1].x)[s], (&q[2].x)[s] }, hi[3] = { (&q[3].x)[s], (&q[4].x)[s], (&q[5].x)[s] };
+            if (cr >= 0) cost += halfArea(lo, hi) / rootArea;
+            Box c = walk(cr, depth + 1);
+            for (int k = 0; k < 3; ++k) {
+                const float tol = 1e-5f * (std::fabs(c.lo[k]) + std::fabs(c.hi[k]) + 1.0f);
+                if (c.lo[k] < lo[k] - tol || c.hi[k] > hi[k] + tol) ok = false;
+                b.lo[k] = std::min(b.lo[k], lo[k]); b.hi[k] = std::max(b.hi[k], hi[k]);
+            }
+        }
+        return b;
+    };
+    walk(0, 0);
+    if (!ok) { pt_set_error("pt_bvh_device_layout: a child box does not hold the triangles below it"); return PT_EINVAL; }
+    std::vector<char> rankSeen(ntri, 0);
+    for (int i = 0; i < ntri; ++i) {
+        if (fm.leafOfOrig.size() && refs[i] != 1) { pt_set_error("pt_bvh_device_layout: triangle slot %d is referenced %d times", i, refs[i]); return PT_EINVAL; }
+        int rank; float f = fm.hot[3 * (size_t)i + 2].z; memcpy(&rank, &f, 4);
+        if (rank < 0 || rank >= ntri || rankSeen[rank]) { pt_set_error("pt_bvh_device_layout: visit ranks are not a permutation"); return PT_EINVAL; }
+        rankSeen[rank] = 1;
+        out->trianglesReferenced += refs[i];
+    }
+    double hostCost = 0.0;
+    for (int i = 0; i < nn; ++i)
+        if (nodes[i].leftChild != -1 && i != 0) hostCost += halfArea(nodes[i].bmin, nodes[i].bmax) / rootArea;
+    out->wideDepth = maxDepth;
+    out->sahCostHost = (float)hostCost;
+    out->sahCostDevice = (float)cost;
+    return PT_OK;
+}
 
 int pt_destroy(PtContext* c)
 {
