@@ -158,7 +158,7 @@ def main():
         # + 28 B hit record written, plus its own box / triangle / attribute bytes (exact counts from
         # the counted pass over the first iterations of the timed range).
         stages = {"k_trace(closest)": st.msTrace, "k_trace(shadow)": st.msShadowTrace,
-                  "intersect_other(k_cull+k_prims)": st.msIntersect - st.msTrace,
+                  "k_prims": st.msIntersect - st.msTrace,
                   "k_shade": st.msShade - st.msShadowTrace, "sort": st.msSort, "compact": st.msCompact}
         per_ray = 1.0 / max(counted["rays"], 1)
         boxes, tris, hits = counted["boxes"] * per_ray, counted["tris"] * per_ray, counted["hits"] * per_ray

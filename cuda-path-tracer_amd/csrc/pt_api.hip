@@ -21,14 +21,14 @@ using namespace ptd;
 
 void pt_set_error(const char* fmt, ...);
 
-void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q);
+void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount);
 void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount);
 void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
                uint32_t* fetchCtr, const uint32_t* workCount, void* dc);
 void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-               uint32_t* shadowCount, void* dc);
+               uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc);
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride);
@@ -144,7 +144,7 @@ int allocBatchState(PtContext* c, int batch)
 #define BA(ptr, count, zero) if ((rc = batchAlloc(c, &(ptr), (count), (zero))) != PT_OK) return rc
     BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
     BA(P.hitA, N * B, false); BA(P.hitB, N * B, false); BA(P.hitTri, N * B, false);
-    BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.workQueue, N * B, false);
+    BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.workQueue, N * B, false); BA(P.traceQueue, N * B, false);
     BA(P.image, N * B * 3, true);
     BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);
     BA(Q.blockHist, (size_t)Q.numBuckets * Q.numBlocks * B, false);
@@ -884,13 +884,12 @@ static int traceBatch(PtContext* c, Batch bt)
         PathState st = c->state.at(r0);
         Queues q = c->queues.at(r0);
         const size_t rowOff = (size_t)r0 * kCtrStride;
-        { SpanGuard sg(c, ST_CAMERA, gs); ptl_camera(gs, c->cam, gb, c->traceDepth, st, q); }
+        { SpanGuard sg(c, ST_CAMERA, gs); ptl_camera(gs, V, c->cam, gb, c->traceDepth, st, q, closestCount + rowOff); }
         for (int b = 0; b < c->traceDepth; ++b) {
             const size_t row = (size_t)b * kMaxBatch * kCtrStride + rowOff;
             {
                 SpanGuard sg(c, ST_INTERSECT, gs);
                 if (meshes) {
-                    ptl_cull(gs, V, st, q, gb, b, closestCount + row);
                     SpanGuard t(c, ST_TRACE, gs);
                     ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + row, closestCount + row, c->dc);
                 }
@@ -899,7 +898,8 @@ static int traceBatch(PtContext* c, Batch bt)
             if (c->sortOn) { SpanGuard sg(c, ST_SORT, gs); ptl_sort(gs, q, gb, b, V.numBuckets); }
             {
                 SpanGuard sg(c, ST_SHADE, gs);
-                ptl_shade(gs, V, st, q, gb, b, c->sortOn, count, shadowCount + row, c->dc);
+                ptl_shade(gs, V, st, q, gb, b, c->sortOn, count, shadowCount + row,
+                          (meshes && b + 1 < c->traceDepth) ? closestCount + row + (size_t)kMaxBatch * kCtrStride : nullptr, c->dc);
                 if (meshes) {
                     SpanGuard t(c, ST_SHADOW_TRACE, gs);
                     ptl_trace(gs, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
@@ -1111,7 +1111,9 @@ int pt_camera_rays(PtContext* c, int iter, float* origins, float* directions)
     HIP_TRY(hipMalloc((void**)&dO, (size_t)n * 12));
     if (hipMalloc((void**)&dD, (size_t)n * 12) != hipSuccess) { (void)hipFree(dO); pt_set_error("pt_camera_rays: out of device memory"); return PT_ENOMEM; }
     Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
-    ptl_camera(c->stream, c->cam, bt, c->traceDepth, c->state, c->queues);
+    SceneView V = c->view;
+    V.numBvhMeshes = 0;          /* no work list wanted here */
+    ptl_camera(c->stream, V, c->cam, bt, c->traceDepth, c->state, c->queues, nullptr);
     ptl_export_rays(c->stream, c->state, n, dO, dD);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(origins, dO, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream);

@@ -71,15 +71,17 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
  * One thread per pixel: 2x2 stratified jitter cell = iter % 4, two draws from the
  * (iter, pixel, 0) stream, pinhole direction (generateRayFromCamera,
  * src/pathtrace.cu:694-745). */
-__global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int traceDepth, PathState st, Queues q)
+__global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Batch bt, int traceDepth, PathState st, Queues q, uint32_t* traceCount)
 {
+    __shared__ int s_tmp[kBlock / 64 + 1];
     st = st.at(blockIdx.y);
     uint32_t* live = q.at(blockIdx.y).live;
     const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
     const int W = cam.resolution[0], H = cam.resolution[1];
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index == 0) live[0] = (uint32_t)(W * H);
-    if (index >= W * H) return;
+    bool cand = false;
+    if (index < W * H) {
     const int x = index % W, y = index / W;
     Lcg rng;
     rng.seed(iter, index, 0);
@@ -95,6 +97,16 @@ __global__ void __launch_bounds__(kBlock) k_camera(PtCamera cam, Batch bt, int t
     st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
     st.rayD[index] = make_float4(dir.x, dir.y, dir.z, 0.0f);
     st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
+    /* work list of the first closest-hit traversal (see k_cull) */
+    if (S.numBvhMeshes > 0) {
+        Ray r; r.o = f3(cam.position); r.d = dir;
+        cand = mayHitBvhMeshes(S, r, __builtin_inff());
+    }
+    }
+    if (S.numBvhMeshes > 0) {
+        const int at = blockAppendIndex(cand, traceCount + blockIdx.y * kCtrStride, s_tmp);
+        if (at >= 0) st.traceQueue[at] = index;
+    }
 }
 
 /* --------------------------------------------------------------- intersect
@@ -140,10 +152,12 @@ PT_DEV int nextBvhMesh(const SceneView& S, int from)
 
 enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1 };
 
-/* Work list of the closest-hit traversal: rays that may hit a BVH mesh go to the work queue (one
- * atomic per wave; the order is free, results are stored by pixel), all others get their "no mesh
- * hit" record here.  Most rays of a typical bounce never come near a mesh; keeping them out of the
- * traversal kernel keeps its lanes busy with rays that actually walk a tree. */
+/* Work list of the closest-hit traversal: rays that may hit a BVH mesh go to the trace queue (one
+ * atomic per workgroup; the order is free, results are stored by pixel); k_prims repeats the test and
+ * does not look for a mesh result for the others.  Most rays of a typical bounce never come near a
+ * mesh; keeping them out of the traversal kernel keeps its lanes busy with rays that actually walk a
+ * tree.  Inside the loop the stage that creates a ray (k_camera, k_shade) files it; this kernel does it
+ * for rays that arrive from outside (the fixed-ray-set hook). */
 __global__ void __launch_bounds__(kBlock) k_cull(SceneView S, PathState st, Queues q, int bounce, uint32_t* workCount)
 {
     __shared__ int s_tmp[kBlock / 64 + 1];
@@ -159,14 +173,9 @@ __global__ void __launch_bounds__(kBlock) k_cull(SceneView S, PathState st, Queu
         float4 o = st.rayO[pix], d = st.rayD[pix];
         Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
         cand = mayHitBvhMeshes(S, r, __builtin_inff());
-        if (!cand) {
-            st.hitA[pix] = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
-            st.hitB[pix] = make_float4(__int_as_float(0), 0.0f, 0.0f, __int_as_float(-1));
-            st.hitTri[pix] = -1;
-        }
     }
     const int idx = blockAppendIndex(cand, workCount + blockIdx.y * kCtrStride, s_tmp);
-    if (idx >= 0) st.workQueue[idx] = pix;
+    if (idx >= 0) st.traceQueue[idx] = pix;
 }
 
 /* items: work queue entries [0, workCount[row]) */
@@ -256,7 +265,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     const uint32_t sidx = base + (uint32_t)__builtin_popcountll(fm & lt);
                     if (sidx < n) {
                         if (MODE == TRACE_CLOSEST) {
-                            pix = st.workQueue[sidx];
+                            pix = st.traceQueue[sidx];
                             float4 o = st.rayO[pix], d = st.rayD[pix];
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
@@ -325,7 +334,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
         float4 o = st.rayO[pix], d = st.rayD[pix];
         Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
         Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
-        if (S.numBvhMeshes > 0) {
+        if (S.numBvhMeshes > 0 && mayHitBvhMeshes(S, r, __builtin_inff())) {      /* the ray was filed for traversal */
             float4 ha = st.hitA[pix], hb = st.hitB[pix];
             best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
             best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
@@ -463,7 +472,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, i
  * shadow mode settles it (before the next stage reads the colour). */
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S, PathState st, Queues q, Batch bt, int bounce, int sortOn,
-                                                                     uint32_t* shadowCount, DevCounters* dc)
+                                                                     uint32_t* shadowCount, uint32_t* nextTraceCount, DevCounters* dc)
 {
     __shared__ int s_alive[kBlock / 64];
     __shared__ int s_tmp[kBlock / 64 + 1];
@@ -481,6 +490,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     ShadowReq sq;
     sq.pending = false; sq.o = f3(0.0f); sq.d = f3(0.0f); sq.dist = 0.0f; sq.lightGeom = -1; sq.colorVisible = f3(0.0f);
     int pix = 0;
+    Ray newRay; newRay.o = f3(0.0f); newRay.d = f3(0.0f);
     if (active) {
         pix = (!sortOn && bounce == 0) ? slot : queue[slot];
         float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
@@ -493,6 +503,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0, sq, cnt);
         alive = p.remaining > 0;
         if (alive) {
+            newRay.o = p.o; newRay.d = p.d;
             st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
             st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, 0.0f);
         }
@@ -504,6 +515,13 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
             im[0] += p.color.x; im[1] += p.color.y; im[2] += p.color.z;
         }
         queue[slot] = alive ? pix : (-1 - pix);
+    }
+    /* the surviving path's new ray goes on the work list of the next closest-hit traversal */
+    if (nextTraceCount) {
+        bool cand = false;
+        if (alive) cand = mayHitBvhMeshes(S, newRay, __builtin_inff());
+        const int at = blockAppendIndex(cand, nextTraceCount + blockIdx.y * kCtrStride, s_tmp);
+        if (at >= 0) st.traceQueue[at] = pix;
     }
     /* shadow queue append */
     const int shIdx = blockAppendIndex(sq.pending, shadowCount + blockIdx.y * kCtrStride, s_tmp);
@@ -706,9 +724,9 @@ static inline int gridFor(long long n) { return (int)((n + kBlock - 1) / kBlock)
 
 extern "C++" {
 
-void ptl_camera(hipStream_t s, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q)
+void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount)
 {
-    hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1]), bt.count), dim3(kBlock), 0, s, cam, bt, depth, st, q);
+    hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1]), bt.count), dim3(kBlock), 0, s, S, cam, bt, depth, st, q, traceCount);
 }
 static inline int persistentGridX(int batch)
 {
@@ -746,10 +764,10 @@ void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
     hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, numBuckets);
 }
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-               uint32_t* shadowCount, void* dc)
+               uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc)
 {
-    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, (DevCounters*)dc);
+    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
 }
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
 {

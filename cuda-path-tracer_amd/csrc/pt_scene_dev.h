@@ -89,15 +89,16 @@ struct PathState {
     float4* shO;
     float4* shD;
     float4* shC;
-    int* workQueue;                 /* pixels the traversal kernel has to visit, in arrival order: rays that may hit a
-                                       BVH mesh before shading, pending shadow rays after it */
+    int* workQueue;                 /* pixels with a pending shadow ray, in arrival order */
+    int* traceQueue;                /* pixels whose ray may hit a BVH mesh, in arrival order (filled by the stage that
+                                       creates the ray: camera, shade) */
     size_t numPixels;
     __host__ PT_DEV PathState at(int k) const
     {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
         r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.image += 3 * off;
-        r.hitTri += off; r.shO += off; r.shD += off; r.shC += off; r.workQueue += off;
+        r.hitTri += off; r.shO += off; r.shD += off; r.shC += off; r.workQueue += off; r.traceQueue += off;
         return r;
     }
 };
