@@ -386,3 +386,41 @@ def test_pathtrace_surface_headless_driver(pt, scenes, orc, gpu_ok, tmp_path):
             got = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
         assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
         assert got.sum() > 0
+
+
+def test_full_size_properties_dragon_1080p(pt, scenes, gpu_ok):
+    """At the benchmark's own size (1920x1080, depth 8, 135 200 triangles) the oracle is too slow to be the checker,
+    so size-independent properties are: launch groups of any size and stream split give the same bits as one
+    iteration per call; an interleaved sample split over two tracers sums to the single render up to fp32
+    summation order; the path-bounce total equals the sum of the live-path curve; every pixel is finite and >= 0."""
+    sc = scenes.make_scene("dragon", res=(1920, 1080), depth=8)
+    n = 6
+    a = pt.Tracer(sc)
+    for it in range(1, n + 1):
+        a.trace(it)
+    img_a = a.image()
+    sa = a.stats()
+    assert np.isfinite(img_a).all() and (img_a >= 0).all() and img_a.sum() > 0
+    # the last iteration's live curve sums to that iteration's share of the path-bounce total
+    b = pt.Tracer(sc)
+    b.set_option(pt.PT_OPT_BATCH, n)
+    b.trace_range(1, n + 1, 1)
+    sb = b.stats()
+    assert sb.pathBounces == sa.pathBounces
+    assert list(sb.lastLive[:9]) == list(sa.lastLive[:9])
+    assert _same_bits(b.image(), img_a)
+    c = pt.Tracer(sc)
+    c.set_option(pt.PT_OPT_BATCH, 4)
+    c.trace_range(1, n + 1, 1)
+    assert _same_bits(c.image(), img_a)
+    one = pt.Tracer(sc)
+    one.trace(n)
+    so = one.stats()
+    assert so.pathBounces == sum(so.lastLive[:8])
+    # two "ranks": iterations 1,3,5 and 2,4,6
+    r0, r1 = pt.Tracer(sc), pt.Tracer(sc)
+    r0.trace_range(1, n + 1, 2)
+    r1.trace_range(2, n + 1, 2)
+    assert r0.stats().pathBounces + r1.stats().pathBounces == sa.pathBounces
+    s = r0.image() + r1.image()
+    assert np.allclose(s, img_a, rtol=1e-5, atol=1e-5)
