@@ -424,3 +424,29 @@ def test_full_size_properties_dragon_1080p(pt, scenes, gpu_ok):
     assert r0.stats().pathBounces + r1.stats().pathBounces == sa.pathBounces
     s = r0.image() + r1.image()
     assert np.allclose(s, img_a, rtol=1e-5, atol=1e-5)
+
+
+def test_gpu_reproduces_committed_vectors(pt, scenes, gpu_ok):
+    """The committed oracle vectors (tests/golden/oracle_vectors.npz), without the oracle in the loop: closest hits on the
+    stored ray set and whole iterations, bit for bit, on the analytic scene and on the stored two-mesh scene."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "oracle_vectors.npz"))
+    ro, rd = g["ray_o"], g["ray_d"]
+    sc = scenes.make_scene("cornell", res=(48, 48), depth=8)
+    tr = pt.Tracer(sc)
+    _hits_equal(tr.intersect(ro, rd), g["cornell_hits"])
+    for it in (1, 2, 3):
+        tr.trace(it)
+    assert _same_bits(tr.image(), g["cornell_det_image"])
+    st = tr.stats()
+    assert int(st.pathBounces) == int(g["cornell_det_path_bounces"])
+    assert list(st.lastLive[:9]) == list(g["cornell_det_live"][2])
+    sc = make_golden.build_mesh_scene(pt, scenes, g["blob"], g["cube"], (40, 40))
+    tr = pt.Tracer(sc)
+    _hits_equal(tr.intersect(ro, rd), g["mesh_hits"])
+    tr.trace_range(1, 3, 1)
+    assert _same_bits(tr.image(), g["mesh_det_image"])
+    assert int(tr.stats().pathBounces) == int(g["mesh_det_path_bounces"])

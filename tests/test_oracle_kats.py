@@ -2,6 +2,7 @@
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -152,3 +153,40 @@ def test_duck_bvh_statistics(pt, scenes, orc):
         assert abs(st["nodes"] - k["nodes"]) <= 8 and abs(st["leaves"] - k["leaves"]) <= 4
         assert abs(st["max_depth"] - k["max_depth"]) <= 1
         assert sorted(idx.tolist()) == list(range(len(tris)))
+
+
+def _golden():
+    return np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
+
+
+def test_oracle_reproduces_committed_vectors(pt, scenes, orc):
+    """tests/golden/oracle_vectors.npz (written by tests/golden/make_golden.py): the oracle's deterministic mode is
+    bit-stable; its libm mode depends on the C library's sinf/cosf/..., so that image is compared with a tolerance."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = _golden()
+    ro, rd = g["ray_o"], g["ray_d"]
+    sc = scenes.make_scene("cornell", res=(48, 48), depth=8)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    h = o.intersect(ro, rd)
+    assert h.tobytes() == g["cornell_hits"].tobytes()
+    for it in (1, 2, 3):
+        o.trace(it)
+    assert o.image().tobytes() == g["cornell_det_image"].tobytes()
+    assert int(o.stats().pathBounces) == int(g["cornell_det_path_bounces"])
+    assert list(o.stats().lastLive[:9]) == list(g["cornell_det_live"][2])
+    o.close()
+    o = orc.Oracle(pt, sc, orc.MATH_LIBM)
+    for it in (1, 2, 3):
+        o.trace(it)
+    ref = g["cornell_libm_image"]
+    rmse = float(np.sqrt(np.mean((o.image() - ref) ** 2))) / float(ref.mean())
+    assert rmse < 0.02, rmse
+    o.close()
+    sc = make_golden.build_mesh_scene(pt, scenes, g["blob"], g["cube"], (40, 40))
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    assert o.intersect(ro, rd).tobytes() == g["mesh_hits"].tobytes()
+    for it in (1, 2):
+        o.trace(it)
+    assert o.image().tobytes() == g["mesh_det_image"].tobytes()
+    o.close()
