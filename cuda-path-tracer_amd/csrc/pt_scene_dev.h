@@ -205,10 +205,14 @@ PT_DEV float hitSphere(const DGeom& g, const Ray& r, F3& N)
 }
 
 /* Moller-Trumbore on a hot triangle record (src/intersections.cu:268-308) */
+PT_DEV float hitTriangleRec(float4 a, float4 b, float4 c, F3 lo, F3 ld, F3& bary);
 PT_DEV float hitTriangle(const float4* hot, F3 lo, F3 ld, F3& bary)
 {
+    return hitTriangleRec(hot[0], hot[1], hot[2], lo, ld, bary);
+}
+PT_DEV float hitTriangleRec(float4 a, float4 b, float4 c, F3 lo, F3 ld, F3& bary)
+{
     const float EPS = 0.0000001f;
-    float4 a = hot[0], b = hot[1], c = hot[2];
     F3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
     F3 h = cross(ld, e2);
     float det = dot(e1, h);
@@ -343,15 +347,21 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         if (!leafTurn) return true;     /* hold the leaf until enough lanes of the wave have one */
         const unsigned x = ~(unsigned)ref;
         const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
+        /* the next triangle's record is requested before the current one is tested: one memory round trip
+         * per leaf instead of one per triangle */
+        const float4* tp = S.triHot + 3 * ((size_t)tv.triStart + (size_t)first);
+        float4 ra = tp[0], rb = tp[1], rc = tp[2];
         for (int i = 0; i < count; ++i) {
+            float4 na = ra, nb = rb, nc = rc;
+            if (i + 1 < count) { na = tp[3 * (i + 1)]; nb = tp[3 * (i + 1) + 1]; nc = tp[3 * (i + 1) + 2]; }
             F3 bary;
-            const float4* tp = S.triHot + 3 * ((size_t)tv.triStart + (size_t)(first + i));
-            float tt = hitTriangle(tp, tv.lo, tv.ld, bary);
+            float tt = hitTriangleRec(ra, rb, rc, tv.lo, tv.ld, bary);
             if (COUNT) cnt.tris++;
             if (tt > 0.0f && !(tt > tv.closestT)) {
-                int rank = __float_as_int(tp[2].z);
+                int rank = __float_as_int(rc.z);
                 if (tt < tv.closestT || rank < tv.bestRank) { tv.closestT = tt; tv.bary = bary; tv.best = first + i; tv.bestRank = rank; }
             }
+            ra = na; rb = nb; rc = nc;
         }
     }
     /* pop the next entry that can still hold a closer (or equal) hit */
