@@ -1081,7 +1081,7 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
         const int m = std::min(chunk, n - first);
         hipError_t e = hipMemcpyAsync(dO, origins + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, kCtrStride * sizeof(uint32_t), c->stream);     /* the whole counter line */
         if (e == hipSuccess) e = hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) {
             Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;

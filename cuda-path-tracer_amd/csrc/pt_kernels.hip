@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #define PT_LEAF_WAIT 24
 #endif
 constexpr int kRefillThreshold = PT_REFILL;
+constexpr int kSegments = 8;          /* pieces of a work queue = XCDs (private L2s) of the device */
 constexpr int kLeafWait = PT_LEAF_WAIT;
 
 PT_DEV int nextBvhMesh(const SceneView& S, int from)
@@ -190,7 +191,14 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     q = q.at(blockIdx.y);
     const uint32_t n = workCount[blockIdx.y * kCtrStride];
     if (n == 0) return;
+    /* The work queue is cut into kSegments contiguous pieces with a fetch counter each (dwords 0..7 of the row's
+     * counter line).  Workgroups are dealt round-robin over the 8 XCDs, so (linear workgroup id) % 8 names the
+     * groups that share an L2: each starts on "its" piece and moves on to the others when that runs dry.  Queues
+     * are filed in pixel / slot order, so a piece is a coherent part of the image and an XCD's L2 mostly sees one
+     * part of the BVH. */
     uint32_t* ctr = fetchCtr + blockIdx.y * kCtrStride;
+    int seg = (int)((blockIdx.y * gridDim.x + blockIdx.x) % kSegments);
+    int segsLeft = kSegments;
     int* stack = s_stack + tid;
     int ovRef[kOverflowStack];
     float ovT[kOverflowStack];
@@ -254,16 +262,24 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     }
                 }
             }
-            const unsigned long long fm = __ballot(fetch);
-            if (COUNT) { diag[4]++; diag[5] += __builtin_popcountll(fm); }
-            if (fm) {
+            if (COUNT) { diag[4]++; diag[5] += __builtin_popcountll(__ballot(fetch)); }
+            while (true) {
+                const unsigned long long fm = __ballot(fetch);
+                if (fm == 0) break;
+                if (segsLeft == 0) { if (fetch) exhausted = true; break; }
+                const uint32_t segBegin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / kSegments);
+                const uint32_t segLen = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / kSegments) - segBegin;
+                const uint32_t want = (uint32_t)__builtin_popcountll(fm);
                 const int leader = __builtin_ctzll(fm);
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(ctr, (uint32_t)__builtin_popcountll(fm));
+                if (lane == leader) base = atomicAdd(ctr + seg, want);
                 base = (uint32_t)__shfl((int)base, leader);
+                if (base + want >= segLen) { seg = (seg + 1) % kSegments; --segsLeft; }     /* this piece is used up */
                 if (fetch) {
-                    const uint32_t sidx = base + (uint32_t)__builtin_popcountll(fm & lt);
-                    if (sidx < n) {
+                    const uint32_t sloc = base + (uint32_t)__builtin_popcountll(fm & lt);
+                    if (sloc < segLen) {
+                        const uint32_t sidx = segBegin + sloc;
+                        fetch = false;
                         if (MODE == TRACE_CLOSEST) {
                             pix = st.traceQueue[sidx];
                             float4 o = st.rayO[pix], d = st.rayD[pix];
@@ -279,8 +295,6 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                         gi = firstMesh;
                         travInit(S.geoms[gi], r, tv);
                         trav = true;
-                    } else {
-                        exhausted = true;
                     }
                 }
             }
