@@ -213,7 +213,7 @@ def main():
                         "stage_ms_per_spp": roofline["stage_ms_per_spp"], "measured_in": roofline["measured_in"]}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as orc                    # the checker, timed as the CPU baseline only
             o = orc.Oracle(pt, sc, orc.MATH_LIBM)
