@@ -1,21 +1,24 @@
 /*
  * pt_kernels.hip — gfx950 kernels of the wavefront loop and their launchers.
  *
- * One iteration (= one sample per pixel) runs, per bounce b:
- *   k_intersect      closest hit for queue slots [0, live[b]); writes the hit record by
- *                    pixel, the sort bucket by slot, and this workgroup's bucket histogram
- *   k_sort_scan      exclusive scan of the (bucket-major, workgroup-minor) histogram
- *   k_sort_scatter   stable counting sort of the 4-byte pixel queue by material bucket
- *   k_shade          shades slot i = sorted position (the index the RNG is seeded with),
- *                    adds terminated paths to the image, flags survivors in the queue
+ * A launch group holds up to 256 iterations (= samples per pixel), one grid row each; per bounce b
+ * every row runs:
+ *   k_trace<closest>  persistent BVH traversal over the rays filed for it (by k_camera for b = 0, by
+ *                     k_shade afterwards): closest mesh hit by pixel
+ *   k_prims           boxes, spheres, linear-scan meshes folded in; final hit record by pixel, sort
+ *                     bucket by slot, this workgroup's bucket histogram
+ *   k_sort_scan       exclusive scan of the (bucket-major, workgroup-minor) histogram
+ *   k_sort_scatter    stable counting sort of the 4-byte pixel queue by material bucket
+ *   k_shade           shades slot i = sorted position (the index the RNG is seeded with), adds
+ *                     terminated paths to the image, flags survivors in the queue, files the new
+ *                     ray for the next traversal and open shadow rays for the shadow traversal
+ *   k_trace<shadow>   BVH part of the shadow rays; settles the path colour
  *   k_compact_scan / k_compact_scatter   order-preserving compaction of the queue
- * All launches use a fixed grid and read the live count from device memory, so the host
- * never waits for a count (the reference synchronises >= 5 times per bounce,
- * src/pathtrace.cu:2729-2879).
+ * All launches use a fixed grid and read their item counts from device memory, so the host never
+ * waits for a count (the reference synchronises >= 5 times per bounce, src/pathtrace.cu:2729-2879).
  *
- * Wave64 throughout: ranks come from 64-bit ballots + popcount, block-level carries
- * go through LDS, the per-ray traversal stack is a [32][256] LDS array (one conflict-free
- * column per lane).
+ * Wave64 throughout: ranks come from 64-bit ballots + popcount, block-level carries go through
+ * LDS, the per-ray traversal stack is a [32][256] LDS array (one conflict-free column per lane).
  */
 #include "pt_scene_dev.h"
 
