@@ -209,9 +209,10 @@ typedef struct PtHit {
 enum PtOption {
     PT_OPT_MATERIAL_SORT = 1,    /* MATERIAL_SORTING, src/pathtrace.h:6 (default 1) */
     PT_OPT_USE_BVH = 2,          /* USE_BVH, src/pathtrace.cu:193 (default 1)       */
-    PT_OPT_STAGE_TIMING = 3,     /* bracket every stage with HIP events (default 0) */
+    PT_OPT_STAGE_TIMING = 3,     /* bracket every stage with HIP events (default 0);
+                                    while on, a launch group stays on one stream    */
     PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
-    PT_OPT_USE_GRAPH = 5,        /* replay the iteration from a hipGraph (default 0)*/
+    PT_OPT_USE_GRAPH = 5,        /* reserved (hipGraph replay); accepted, no effect */
     PT_OPT_BATCH = 6             /* iterations that share one launch group in
                                     pt_trace_range (default 16, at most 256); results
                                     do not depend on it                              */
@@ -230,8 +231,10 @@ int pt_destroy(PtContext* ctx);
 int pt_trace(PtContext* ctx, int iter);
 
 /* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end.  Up to
- * PT_OPT_BATCH iterations run through the same kernel launches (each with its own
- * queue, so results equal one pt_trace call per iteration, bit for bit). */
+ * PT_OPT_BATCH iterations form a launch group that runs through the same kernel
+ * launches (each iteration with its own path state and queues, so results equal one
+ * pt_trace call per iteration, bit for bit); a group is spread over two streams
+ * internally (environment PT_STREAMS, 1..8) and joined on the context's stream. */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE
