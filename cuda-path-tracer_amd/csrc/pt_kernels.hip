@@ -97,14 +97,14 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
     float py = (float)y + jy - 0.5f;
     F3 dir = normalize(f3(cam.view) - f3(cam.right) * cam.pixelLength[0] * (px - (float)W * 0.5f)
                        - f3(cam.up) * cam.pixelLength[1] * (py - (float)H * 0.5f));
-    st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
-    st.rayD[index] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-    st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
-    /* work list of the first closest-hit traversal (see k_cull) */
+    /* work list of the first closest-hit traversal (see k_cull); the verdict travels with the ray (rayD.w) */
     if (S.numBvhMeshes > 0) {
         Ray r; r.o = f3(cam.position); r.d = dir;
         cand = mayHitBvhMeshes(S, r, __builtin_inff());
     }
+    st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
+    st.rayD[index] = make_float4(dir.x, dir.y, dir.z, __int_as_float(cand ? 1 : 0));
+    st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
     }
     if (S.numBvhMeshes > 0) {
         const int at = blockAppendIndex(cand, traceCount + blockIdx.y * kCtrStride, s_tmp);
@@ -157,7 +157,7 @@ PT_DEV int nextBvhMesh(const SceneView& S, int from)
 enum { TRACE_CLOSEST = 0, TRACE_SHADOW = 1 };
 
 /* Work list of the closest-hit traversal: rays that may hit a BVH mesh go to the trace queue (one
- * atomic per workgroup; the order is free, results are stored by pixel); k_prims repeats the test and
+ * atomic per workgroup; the order is free, results are stored by pixel) and are marked in rayD.w; k_prims
  * does not look for a mesh result for the others.  Most rays of a typical bounce never come near a
  * mesh; keeping them out of the traversal kernel keeps its lanes busy with rays that actually walk a
  * tree.  Inside the loop the stage that creates a ray (k_camera, k_shade) files it; this kernel does it
@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(kBlock) k_cull(SceneView S, PathState st, Queu
         float4 o = st.rayO[pix], d = st.rayD[pix];
         Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
         cand = mayHitBvhMeshes(S, r, __builtin_inff());
+        st.rayD[pix] = make_float4(d.x, d.y, d.z, __int_as_float(cand ? 1 : 0));
     }
     const int idx = blockAppendIndex(cand, workCount + blockIdx.y * kCtrStride, s_tmp);
     if (idx >= 0) st.traceQueue[idx] = pix;
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
         float4 o = st.rayO[pix], d = st.rayD[pix];
         Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
         Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
-        if (S.numBvhMeshes > 0 && mayHitBvhMeshes(S, r, __builtin_inff())) {      /* the ray was filed for traversal */
+        if (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0) {      /* the ray was filed for traversal */
             float4 ha = st.hitA[pix], hb = st.hitB[pix];
             best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
             best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     ShadowReq sq;
     sq.pending = false; sq.o = f3(0.0f); sq.d = f3(0.0f); sq.dist = 0.0f; sq.lightGeom = -1; sq.colorVisible = f3(0.0f);
     int pix = 0;
-    Ray newRay; newRay.o = f3(0.0f); newRay.d = f3(0.0f);
+    bool cand = false;
     if (active) {
         pix = (!sortOn && bounce == 0) ? slot : queue[slot];
         float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
@@ -520,9 +521,10 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0, sq, cnt);
         alive = p.remaining > 0;
         if (alive) {
-            newRay.o = p.o; newRay.d = p.d;
+            /* the surviving path's new ray goes on the work list of the next closest-hit traversal if it can hit a mesh */
+            if (nextTraceCount) { Ray nr; nr.o = p.o; nr.d = p.d; cand = mayHitBvhMeshes(S, nr, __builtin_inff()); }
             st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
-            st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, 0.0f);
+            st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(cand ? 1 : 0));
         }
         if (alive || sq.pending) {
             st.col[pix] = make_float4(p.color.x, p.color.y, p.color.z, __int_as_float(p.remaining));
@@ -533,10 +535,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         }
         queue[slot] = alive ? pix : (-1 - pix);
     }
-    /* the surviving path's new ray goes on the work list of the next closest-hit traversal */
     if (nextTraceCount) {
-        bool cand = false;
-        if (alive) cand = mayHitBvhMeshes(S, newRay, __builtin_inff());
         const int at = blockAppendIndex(cand, nextTraceCount + blockIdx.y * kCtrStride, s_tmp);
         if (at >= 0) st.traceQueue[at] = pix;
     }
