@@ -73,7 +73,10 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 /* ------------------------------------------------------------------ camera
  * One thread per pixel: 2x2 stratified jitter cell = iter % 4, two draws from the
  * (iter, pixel, 0) stream, pinhole direction (generateRayFromCamera,
- * src/pathtrace.cu:694-745). */
+ * src/pathtrace.cu:694-745).  Threads walk the image in 8x8 tiles (a wave = one tile), so the
+ * work list of the first traversal is filed tile by tile and the 64 rays a traversal wave picks
+ * up together cross the same part of the scene; everything a pixel owns (RNG stream, state
+ * slot) is addressed by its row-major index as before. */
 __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Batch bt, int traceDepth, PathState st, Queues q, uint32_t* traceCount)
 {
     __shared__ int s_tmp[kBlock / 64 + 1];
@@ -81,11 +84,13 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
     uint32_t* live = q.at(blockIdx.y).live;
     const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
     const int W = cam.resolution[0], H = cam.resolution[1];
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index == 0) live[0] = (uint32_t)(W * H);
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int tilesX = (W + 7) >> 3;
+    const int tile = t >> 6, x = ((tile % tilesX) << 3) + (t & 7), y = ((tile / tilesX) << 3) + ((t >> 3) & 7);
+    const int index = y * W + x;
+    if (t == 0) live[0] = (uint32_t)(W * H);
     bool cand = false;
-    if (index < W * H) {
-    const int x = index % W, y = index / W;
+    if (x < W && y < H) {
     Lcg rng;
     rng.seed(iter, index, 0);
     const int cell = iter % 4;
@@ -742,7 +747,8 @@ extern "C++" {
 
 void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount)
 {
-    hipLaunchKernelGGL(k_camera, dim3(gridFor((long long)cam.resolution[0] * cam.resolution[1]), bt.count), dim3(kBlock), 0, s, S, cam, bt, depth, st, q, traceCount);
+    const long long tiles = (long long)((cam.resolution[0] + 7) / 8) * ((cam.resolution[1] + 7) / 8);
+    hipLaunchKernelGGL(k_camera, dim3(gridFor(tiles * 64), bt.count), dim3(kBlock), 0, s, S, cam, bt, depth, st, q, traceCount);
 }
 static inline int persistentGridX(int batch)
 {
