@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one launch group of the wavefront loop on every rank: --spp-per-step iterations (one sample per
-pixel each, default 64) that share every kernel launch.  Ranks render disjoint, interleaved iteration
+pixel each, default 128) that share every kernel launch.  Ranks render disjoint, interleaved iteration
 indices of the same replicated scene (iterations are independent given the iteration index, which seeds
 every RNG stream); after the timed steps the per-rank running sums are summed with one all-reduce over
 RCCL.  value = path-bounces of all ranks / time (path-bounce = one live
@@ -42,9 +42,11 @@ VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CUs x 128 lanes x 2 flop 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=64, help="iterations sharing one launch group = one step (1..256)")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="iterations sharing one launch group = one step (1..256); 0 = 128, or fewer so that the path state of a "
+                         "group stays below 100 GB (63 at 3840x2160)")
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -93,7 +95,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    B = max(1, min(args.spp_per_step, 256))
+    B = args.spp_per_step if args.spp_per_step > 0 else max(8, min(128, int(100e9 // (npix * 190.0))))
+    B = max(1, min(B, 256))
 
     def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...; B of them per step
         return 1 + rank + step * B * world
@@ -129,7 +132,7 @@ def main():
 
     # ---- kernel durations for the roofline: the same K steps once more with every stage bracketed by HIP events
     # on the tracer's stream (with stage timing on, the library keeps a launch group on ONE stream, so a kernel's
-    # duration is that of the kernel running alone; the timed region above spreads each group over two streams)
+    # duration is that of the kernel running alone; the timed region above spreads each group over three streams)
     tr.reset_stats()
     tr.set_option(pt.PT_OPT_STAGE_TIMING, 1)
     p0 = time.perf_counter()
@@ -194,7 +197,7 @@ def main():
                     "loop_alg_gbs": round(b_loop * total_pb / world / elapsed / 1e9, 1),
                     "stage_ms_per_spp": {k: round(v / (args.steps * B), 4) for k, v in stages.items()},
                     "measured_in": "a second pass over the same %d steps with HIP events around every stage and the launch group on one "
-                                   "stream (%.3f ms per spp; the timed region overlaps two half-groups on two streams)"
+                                   "stream (%.3f ms per spp; the timed region spreads each group over three streams)"
                                    % (args.steps, (p1 - p0) / (args.steps * B) * 1e3)}
 
         if st.launchesTrace == 0:

@@ -47,7 +47,7 @@ void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, floa
         }                                                                                          \
     } while (0)
 
-constexpr int kDefaultStreamGroups = 2;
+constexpr int kDefaultStreamGroups = 3;
 constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
 constexpr int kMaxBatch = 256;
 constexpr int kMaxStreamGroups = 8;
@@ -874,7 +874,7 @@ static int traceBatch(PtContext* c, Batch bt)
      * several streams: while one group's traversal kernel drains its last long rays, the kernels of the
      * other groups fill the machine.  With stage timing on everything stays on one stream so that the
      * event-bracketed durations are those of kernels running alone. */
-    const int groups = (c->timing || bt.count < 2 * c->streamGroups) ? 1 : c->streamGroups;
+    const int groups = (c->timing || !meshes || bt.count < 2 * c->streamGroups) ? 1 : c->streamGroups;     /* no traversal, no tails to hide */
     if (groups > 1) HIP_TRY(hipEventRecord(c->forkEvent, s));
     for (int g = 0; g < groups; ++g) {
         const int r0 = (int)((long long)bt.count * g / groups), r1 = (int)((long long)bt.count * (g + 1) / groups);

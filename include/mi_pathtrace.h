@@ -233,7 +233,7 @@ int pt_trace(PtContext* ctx, int iter);
 /* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end.  Up to
  * PT_OPT_BATCH iterations form a launch group that runs through the same kernel
  * launches (each iteration with its own path state and queues, so results equal one
- * pt_trace call per iteration, bit for bit); a group is spread over two streams
+ * pt_trace call per iteration, bit for bit); a group is spread over three streams
  * internally (environment PT_STREAMS, 1..8) and joined on the context's stream. */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
