@@ -450,3 +450,24 @@ def test_gpu_reproduces_committed_vectors(pt, scenes, gpu_ok):
     tr.trace_range(1, 3, 1)
     assert _same_bits(tr.image(), g["mesh_det_image"])
     assert int(tr.stats().pathBounces) == int(g["mesh_det_path_bounces"])
+
+
+def test_empty_scene_and_odd_rays(pt, scenes, orc, gpu_ok, tmp_path):
+    """No objects at all (every ray misses: black without an env map, env radiance with one), and rays with zero
+    direction components, origins exactly on box planes and zero-length directions on the mesh scene."""
+    import json
+    d = scenes.scene_dict("cornell")
+    d["Objects"] = []
+    path = str(tmp_path / "empty.json")
+    json.dump(d, open(path, "w"))
+    for env in (False, True):
+        sc = pt.Scene(path)
+        sc.set_resolution(40, 24)
+        if env:
+            sc.set_envmap(scenes.sky_hdr(64, 32), 0.7)
+        _assert_full_parity(pt, orc, sc, [1, 2], lit=env)
+    sc = _three_mesh_scene(pt, scenes, (16, 16))
+    tr, o = pt.Tracer(sc), orc.Oracle(pt, sc)
+    ro = np.array([[0, 4, 9], [0, 4, 9], [-5, 4, 0], [0.2, 12, 0.3], [0, 4, 0], [0, 4, 9], [1.2, 4.5, 9]], np.float32)
+    rd = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 0, 0], [0, 0, -1]], np.float32)
+    _hits_equal(tr.intersect(ro, rd), o.intersect(ro, rd))
