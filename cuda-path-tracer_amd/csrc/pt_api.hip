@@ -73,6 +73,11 @@ struct PtContext {
     int streamGroups = 1;               /* streams the rows of a launch group are spread over */
     hipStream_t groupStreams[kMaxStreamGroups] = {};
     hipEvent_t forkEvent = nullptr, joinEvents[kMaxStreamGroups] = {};
+    /* shadow traversal of bounce b next to the closest-hit stage of bounce b + 1 */
+    hipStream_t shadowStreams[kMaxStreamGroups] = {};
+    hipEvent_t shadedEvents[kMaxStreamGroups] = {}, shadowDoneEvents[kMaxStreamGroups] = {};
+    int shadowOverlap = 1;
+    int rowsPerGroup = 32;              /* a stream group is worth it from this many iterations on */
     PtCamera cam{};
     int traceDepth = 8;
     int numPixels = 0;
@@ -668,6 +673,9 @@ int pt_destroy(PtContext* c)
     for (int g = 0; g < kMaxStreamGroups; ++g) {
         if (c->groupStreams[g]) (void)hipStreamDestroy(c->groupStreams[g]);
         if (c->joinEvents[g]) (void)hipEventDestroy(c->joinEvents[g]);
+        if (c->shadowStreams[g]) (void)hipStreamDestroy(c->shadowStreams[g]);
+        if (c->shadedEvents[g]) (void)hipEventDestroy(c->shadedEvents[g]);
+        if (c->shadowDoneEvents[g]) (void)hipEventDestroy(c->shadowDoneEvents[g]);
     }
     if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -716,7 +724,12 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     for (int g = 0; g < kMaxStreamGroups; ++g) {
         TRY_HIP(hipStreamCreateWithFlags(&c->groupStreams[g], hipStreamNonBlocking));
         TRY_HIP(hipEventCreateWithFlags(&c->joinEvents[g], hipEventDisableTiming));
+        TRY_HIP(hipStreamCreateWithFlags(&c->shadowStreams[g], hipStreamNonBlocking));
+        TRY_HIP(hipEventCreateWithFlags(&c->shadedEvents[g], hipEventDisableTiming));
+        TRY_HIP(hipEventCreateWithFlags(&c->shadowDoneEvents[g], hipEventDisableTiming));
     }
+    { const char* e = getenv("PT_SHADOW_OVERLAP"); if (e) c->shadowOverlap = atoi(e) != 0; }
+    { const char* e = getenv("PT_ROWS_PER_GROUP"); if (e && atoi(e) > 0) c->rowsPerGroup = atoi(e); }
     { const char* e = getenv("PT_STREAMS"); int v = e ? atoi(e) : kDefaultStreamGroups; c->streamGroups = std::max(1, std::min(v, kMaxStreamGroups)); }
 
     /* ---- meshes: concatenated in geom order (src/pathtrace.cu:483-505), one BVH per mesh (:269-334) */
@@ -874,7 +887,7 @@ static int traceBatch(PtContext* c, Batch bt)
      * several streams: while one group's traversal kernel drains its last long rays, the kernels of the
      * other groups fill the machine.  With stage timing on everything stays on one stream so that the
      * event-bracketed durations are those of kernels running alone. */
-    const int groups = (c->timing || !meshes || bt.count < 2 * c->streamGroups) ? 1 : c->streamGroups;     /* no traversal, no tails to hide */
+    const int groups = (c->timing || !meshes) ? 1 : std::max(1, std::min(c->streamGroups, bt.count / c->rowsPerGroup));     /* no traversal, no tails to hide */
     if (groups > 1) HIP_TRY(hipEventRecord(c->forkEvent, s));
     for (int g = 0; g < groups; ++g) {
         const int r0 = (int)((long long)bt.count * g / groups), r1 = (int)((long long)bt.count * (g + 1) / groups);
@@ -885,6 +898,13 @@ static int traceBatch(PtContext* c, Batch bt)
         Queues q = c->queues.at(r0);
         const size_t rowOff = (size_t)r0 * kCtrStride;
         { SpanGuard sg(c, ST_CAMERA, gs); ptl_camera(gs, V, c->cam, gb, c->traceDepth, st, q, closestCount + rowOff); }
+        /* The shadow traversal of a bounce only settles colours and the image; compaction, the next closest-hit
+         * stage and the sort do not look at either.  It therefore runs on a side stream next to them and is
+         * joined before the next shade stage (or the final gather) reads colours again: one more kernel whose
+         * tail of long rays is covered by other work. */
+        const bool side = meshes && !c->timing && c->shadowOverlap && groups == 1;      /* small launch groups only: more streams than three get in each other's way */
+        hipStream_t ss = side ? c->shadowStreams[g] : gs;
+        bool shadowOpen = false;
         for (int b = 0; b < c->traceDepth; ++b) {
             const size_t row = (size_t)b * kMaxBatch * kCtrStride + rowOff;
             {
@@ -897,16 +917,20 @@ static int traceBatch(PtContext* c, Batch bt)
             }
             if (c->sortOn) { SpanGuard sg(c, ST_SORT, gs); ptl_sort(gs, q, gb, b, V.numBuckets); }
             {
+                if (shadowOpen) { HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[g], 0)); shadowOpen = false; }
                 SpanGuard sg(c, ST_SHADE, gs);
                 ptl_shade(gs, V, st, q, gb, b, c->sortOn, count, shadowCount + row,
                           (meshes && b + 1 < c->traceDepth) ? closestCount + row + (size_t)kMaxBatch * kCtrStride : nullptr, c->dc);
                 if (meshes) {
-                    SpanGuard t(c, ST_SHADOW_TRACE, gs);
-                    ptl_trace(gs, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
+                    if (side) { HIP_TRY(hipEventRecord(c->shadedEvents[g], gs)); HIP_TRY(hipStreamWaitEvent(ss, c->shadedEvents[g], 0)); }
+                    SpanGuard t(c, ST_SHADOW_TRACE, ss);
+                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
+                    if (side) { HIP_TRY(hipEventRecord(c->shadowDoneEvents[g], ss)); shadowOpen = true; }
                 }
             }
             { SpanGuard sg(c, ST_COMPACT, gs); ptl_compact(gs, q, gb, b, c->sortOn); }
         }
+        if (shadowOpen) HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[g], 0));
         if (groups > 1) {
             HIP_TRY(hipEventRecord(c->joinEvents[g], gs));
             HIP_TRY(hipStreamWaitEvent(s, c->joinEvents[g], 0));
