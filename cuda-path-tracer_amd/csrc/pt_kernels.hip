@@ -363,10 +363,14 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
             best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
             best.tri = st.hitTri[pix];
         }
+        const bool traced = best.geom >= 0 || (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0);
+        const int meshGeom = best.geom;
         foldInlineGeoms<COUNT>(S, r, best, cnt);
-        st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
-        st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
-        st.hitTri[pix] = best.tri;
+        if (!traced || best.geom != meshGeom) {       /* the traversal's record stands unless an inline geom is closer */
+            st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
+            st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
+            st.hitTri[pix] = best.tri;
+        }
         /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */
         key = (best.t > 0.0f) ? best.mat : (numBuckets - 1);
         if (sortOn) q.keys[slot] = key;
