@@ -50,6 +50,14 @@ PT_DEV int blockAppendIndex(bool flag, uint32_t* counter, int* s_tmp)
     return flag ? idx : -1;
 }
 
+/* The light one-thread-per-slot kernels (sort scatter, compaction, queue copies) are launched with a grid that
+ * is bounded by the machine, not by the image: a workgroup walks "virtual" workgroups vb = blockIdx.x,
+ * blockIdx.x + gridDim.x, ... while they hold live slots.  Late bounces have few live paths; a grid sized for
+ * the whole image would spend its time launching workgroups that exit at once (a quarter of a million per
+ * kernel for 32 iterations at 1080p, about 55 us).  The heavy kernels (k_prims, k_shade) keep one workgroup
+ * per 256 slots: wrapped in such a loop they lose more than the launches cost. */
+#define PT_FOR_VIRTUAL_BLOCKS(vb, n) for (int vb = (int)blockIdx.x; (uint32_t)(vb * kBlock) < (n); vb += (int)gridDim.x)
+
 PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 {
     /* one atomic per wave and counter */
@@ -465,9 +473,9 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, i
     q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
-    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
-    const int slot = blockIdx.x * kBlock + tid;
     const int wave = tid >> 6, lane = laneId();
+    PT_FOR_VIRTUAL_BLOCKS(vb, n) {
+    const int slot = vb * kBlock + tid;
     for (int i = tid; i < (kBlock / 64) * numBuckets; i += kBlock) s_waveCnt[i] = 0;
     __syncthreads();
     const bool active = (uint32_t)slot < n;
@@ -486,9 +494,11 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, i
     }
     __syncthreads();
     if (active) {
-        int base = q.blockHist[(size_t)key * q.numBlocks + blockIdx.x];
+        int base = q.blockHist[(size_t)key * q.numBlocks + vb];
         for (int w = 0; w < wave; ++w) base += s_waveCnt[w * numBuckets + key];
         q.q1[base + rank] = pix;
+    }
+    __syncthreads();
     }
 }
 
@@ -595,19 +605,21 @@ __global__ void __launch_bounds__(kBlock) k_compact_scatter(Queues q, int bounce
     q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
-    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
-    const int slot = blockIdx.x * kBlock + tid;
     const int* src = sortOn ? q.q1 : q.q0;
     int* dst = sortOn ? q.q0 : q.q1;
+    PT_FOR_VIRTUAL_BLOCKS(vb, n) {
+    const int slot = vb * kBlock + tid;
     int e = ((uint32_t)slot < n) ? src[slot] : -1;
     bool alive = e >= 0;
     unsigned long long m = __ballot(alive);
     int rank = (int)__builtin_popcountll(m & laneMaskLt());
     if (laneId() == 0) s_cnt[tid >> 6] = (int)__builtin_popcountll(m);
     __syncthreads();
-    int base = q.blockAlive[blockIdx.x];
+    int base = q.blockAlive[vb];
     for (int w = 0; w < (tid >> 6); ++w) base += s_cnt[w];
     if (alive) dst[base + rank] = e;
+    __syncthreads();
+    }
 }
 
 /* unsorted mode compacts q0 -> q1; copy back so q0 is always the input of the next bounce */
@@ -615,8 +627,10 @@ __global__ void __launch_bounds__(kBlock) k_copy_queue(Queues q, int bounce)
 {
     q = q.at(blockIdx.y);
     const uint32_t n = q.live[bounce + 1];
-    const int slot = blockIdx.x * kBlock + threadIdx.x;
-    if ((uint32_t)slot < n) q.q0[slot] = q.q1[slot];
+    PT_FOR_VIRTUAL_BLOCKS(vb, n) {
+        const int slot = vb * kBlock + threadIdx.x;
+        if ((uint32_t)slot < n) q.q0[slot] = q.q1[slot];
+    }
 }
 
 /* finalGather (src/pathtrace.cu:2630-2639): survivors of the last bounce, normally none */
@@ -625,12 +639,14 @@ __global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q,
     st = st.at(blockIdx.y);
     q = q.at(blockIdx.y);
     const uint32_t n = q.live[depth];
-    const int slot = blockIdx.x * kBlock + threadIdx.x;
-    if ((uint32_t)slot >= n) return;
-    const int pix = q.q0[slot];
-    float4 c = st.col[pix];
-    float* im = st.image + 3 * (size_t)pix;
-    im[0] += c.x; im[1] += c.y; im[2] += c.z;
+    PT_FOR_VIRTUAL_BLOCKS(vb, n) {
+        const int slot = vb * kBlock + threadIdx.x;
+        if ((uint32_t)slot >= n) continue;
+        const int pix = q.q0[slot];
+        float4 c = st.col[pix];
+        float* im = st.image + 3 * (size_t)pix;
+        im[0] += c.x; im[1] += c.y; im[2] += c.z;
+    }
 }
 
 /* per-batch bookkeeping: path-bounce total over the batch, live curve of its last iteration */
@@ -754,6 +770,14 @@ void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt
     const long long tiles = (long long)((cam.resolution[0] + 7) / 8) * ((cam.resolution[1] + 7) / 8);
     hipLaunchKernelGGL(k_camera, dim3(gridFor(tiles * 64), bt.count), dim3(kBlock), 0, s, S, cam, bt, depth, st, q, traceCount);
 }
+/* grid of the light one-thread-per-slot kernels: all rows together about 16k workgroups (see PT_FOR_VIRTUAL_BLOCKS) */
+static inline dim3 slotGrid(const Queues& q, const Batch& bt)
+{
+    int x = (16384 + bt.count - 1) / bt.count;
+    if (x > q.numBlocks) x = q.numBlocks;
+    if (x < 1) x = 1;
+    return dim3(x, bt.count);
+}
 static inline int persistentGridX(int batch)
 {
     static const int total = [] { const char* e = getenv("PT_PERSIST_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
@@ -787,7 +811,7 @@ void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch 
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
 {
     hipLaunchKernelGGL(k_sort_scan, dim3(1, bt.count), dim3(1024), 0, s, q, bounce, numBuckets);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, numBuckets);
+    hipLaunchKernelGGL(k_sort_scatter, slotGrid(q, bt), dim3(kBlock), 0, s, q, bounce, numBuckets);
 }
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
                uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc)
@@ -798,13 +822,13 @@ void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch 
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
 {
     hipLaunchKernelGGL(k_compact_scan, dim3(1, bt.count), dim3(1024), 0, s, q, bounce);
-    hipLaunchKernelGGL(k_compact_scatter, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce, sortOn);
-    if (!sortOn) hipLaunchKernelGGL(k_copy_queue, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, q, bounce);
+    hipLaunchKernelGGL(k_compact_scatter, slotGrid(q, bt), dim3(kBlock), 0, s, q, bounce, sortOn);
+    if (!sortOn) hipLaunchKernelGGL(k_copy_queue, slotGrid(q, bt), dim3(kBlock), 0, s, q, bounce);
 }
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride)
 {
-    hipLaunchKernelGGL(k_final_gather, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, st, q, depth);
+    hipLaunchKernelGGL(k_final_gather, slotGrid(q, bt), dim3(kBlock), 0, s, st, q, depth);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, bt.count, (DevCounters*)dc, shadowCounts, closestCounts, rowStride);
     const size_t n3 = 3 * st.numPixels;
     hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, bt.count);
