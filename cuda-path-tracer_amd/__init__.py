@@ -142,6 +142,9 @@ def _load():
         "pt_scene_set_resolution": (ip, [vp, ip, ip]),
         "pt_scene_set_depth": (ip, [vp, ip]),
         "pt_scene_add_mesh": (ip, [vp, vp, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
+        "pt_scene_import_gltf": (ip, [vp, C.c_char_p, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
+        "pt_scene_log": (C.c_char_p, [vp]),
+        "pt_decode_png": (ip, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "pt_scene_add_material": (ip, [vp, C.POINTER(PtMaterial)]),
         "pt_scene_add_texture": (ip, [vp, vp, ip, ip, ip]),
         "pt_scene_set_envmap": (ip, [vp, vp, ip, ip, fp]),
@@ -214,6 +217,16 @@ def bvh_device_layout(tris, max_depth=24):
         lib.pt_bvh_free(h)
 
 
+def decode_png(data):
+    """PNG bytes -> (H, W, 4) uint8, through the library's own decoder (the texture path of the glTF import)."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_int(), C.c_int()
+    _check(lib.pt_decode_png(buf.ctypes.data, len(buf), None, 0, C.byref(w), C.byref(h)), "pt_decode_png")
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    _check(lib.pt_decode_png(buf.ctypes.data, len(buf), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)), "pt_decode_png")
+    return out
+
+
 class Scene:
     """Owning scene (PtScene): JSON loader + programmatic assembly; no GPU needed."""
 
@@ -267,6 +280,15 @@ class Scene:
         return _check(lib.pt_scene_add_mesh(self._h, tris.ctypes.data, len(tris), _f3(translation), _f3(rotation),
                                             _f3(scale)), "pt_scene_add_mesh")
 
+    def import_gltf(self, path, translation=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1)):
+        """Import a .glb / .gltf file as one mesh object (textures, materials, triangles); returns the geom index."""
+        return _check(lib.pt_scene_import_gltf(self._h, os.fspath(path).encode(), _f3(translation), _f3(rotation),
+                                               _f3(scale)), "pt_scene_import_gltf")
+
+    @property
+    def log(self):
+        return lib.pt_scene_log(self._h).decode()
+
     def set_envmap(self, rgb, intensity=1.0):
         rgb = np.ascontiguousarray(rgb, dtype=np.float32)
         h, w = rgb.shape[:2]
@@ -280,6 +302,27 @@ class Scene:
     def geoms(self):
         d = self.desc.contents
         return [d.geoms[i] for i in range(d.geomCount)]
+
+    def mesh_triangles(self, mesh_index):
+        """Copy of one mesh's triangle records (TRI_DTYPE)."""
+        d = self.desc.contents
+        if not 0 <= mesh_index < d.meshCount:
+            raise IndexError(mesh_index)
+        m = d.meshes[mesh_index]
+        n = int(m.triangleCount)
+        if n == 0:
+            return np.zeros(0, TRI_DTYPE)
+        return np.frombuffer(C.string_at(m.triangles, n * TRI_DTYPE.itemsize), TRI_DTYPE).copy()
+
+    def textures(self):
+        """Copies of the texture table as (H, W, components) uint8 arrays."""
+        d = self.desc.contents
+        out = []
+        for i in range(d.textureCount):
+            t = d.textures[i]
+            n = int(t.width) * int(t.height) * int(t.components)
+            out.append(np.frombuffer(C.string_at(t.data, n), np.uint8).reshape(t.height, t.width, t.components).copy())
+        return out
 
     def close(self):
         if self._h:

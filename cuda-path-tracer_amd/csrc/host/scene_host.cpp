@@ -15,10 +15,13 @@
  *  - a mesh object's Geom.materialid is uninitialised in the reference
  *    (src/scene.cpp:837-885); here it is -1.
  *  - glTF-imported materials leave indexOfRefraction / subsurface* unset
- *    (src/scene.cpp:96); pt_scene_add_material takes fully specified materials.
+ *    (src/scene.cpp:96); pt_scene_add_material takes fully specified materials
+ *    and the glTF importer (gltf_load.cpp) fills them with fixed values.
  */
 #include "../../../include/mi_pathtrace.h"
+#include "gltf_load.h"
 #include "json_min.h"
+#include "png_decode.h"
 #include "xform.h"
 
 #include <cmath>
@@ -62,6 +65,7 @@ struct PtScene {
     float fovy = 45.0f;
     int traceDepth = 8, iterations = 1;
     std::string imageName;
+    std::string log;                    /* loader messages (the reference prints them to stdout) */
     std::vector<float> image;           /* W*H*3 running sum on the host, filled by the pathtrace() shim */
     PtSceneDesc desc{};
 
@@ -284,6 +288,41 @@ std::string dirOf(const std::string& path)
     return s == std::string::npos ? std::string() : path.substr(0, s + 1);
 }
 
+/* Put a triangle list into the first still-empty glTF object with the same TRS, else into a new object. */
+int attachMesh(PtScene* s, std::vector<PtTriangle>&& tris, const float t[3], const float r[3], const float sc[3])
+{
+    int slot = -1;
+    for (size_t i = 0; i < s->geoms.size(); ++i) {
+        PtGeom& g = s->geoms[i];
+        if (g.type == PT_GLTF_MESH && g.meshIndex < 0 && !memcmp(g.translation, t, 12) && !memcmp(g.rotation, r, 12) && !memcmp(g.scale, sc, 12)) { slot = (int)i; break; }
+    }
+    if (slot < 0) { s->geoms.push_back(makeGeom(PT_GLTF_MESH, -1, t, r, sc)); slot = (int)s->geoms.size() - 1; }
+    const int n = (int)tris.size();
+    s->meshTris.emplace_back(std::move(tris));
+    PtMesh m; memset(&m, 0, sizeof(m));
+    s->meshes.push_back(m);
+    s->geoms[slot].meshIndex = (int)s->meshes.size() - 1;
+    s->geoms[slot].triangleCount = n;
+    return slot;
+}
+
+/* Scene::loadGLTFModel (src/scene.cpp:195-568): textures, then materials, then the triangles of every
+ * scene node under the object's TRS.  Nothing is added when the file cannot be read or parsed. */
+int importGltf(PtScene* s, const std::string& path, const float t[3], const float r[3], const float sc[3], std::string& err)
+{
+    ptgltf::Import imp;
+    const ptx::Mat4 root = ptx::buildTransformationMatrix(t, r, sc);
+    if (!ptgltf::load(path, root, (int)s->materials.size(), (int)s->textures.size(), imp, err)) return PT_EIO;
+    for (const auto& w : imp.warnings) s->log += path + ": " + w + "\n";
+    for (auto& img : imp.textures) {
+        PtTexture tx; tx.data = nullptr; tx.width = img.width; tx.height = img.height; tx.components = img.components;
+        s->texData.emplace_back(std::move(img.pixels));
+        s->textures.push_back(tx);
+    }
+    for (const auto& m : imp.materials) { s->materials.push_back(m); s->materialNames.push_back(std::string()); }
+    return attachMesh(s, std::move(imp.triangles), t, r, sc);
+}
+
 } // namespace
 
 extern "C" {
@@ -343,10 +382,17 @@ int pt_scene_load(const char* json_path, PtScene** out)
             if (type == "cube") S->geoms.push_back(makeGeom(PT_CUBE, matId(p.at("MATERIAL").s()), t, r, s));
             else if (type == "sphere") S->geoms.push_back(makeGeom(PT_SPHERE, matId(p.at("MATERIAL").s()), t, r, s));
             else if (type == "gltf") {
-                /* glTF import is not part of this loader: the object is kept as an empty mesh,
-                   which is what the reference is left with when the .glb is missing
-                   (src/scene.cpp:218-226, :885); callers attach geometry with pt_scene_add_mesh */
+                /* src/scene.cpp:863-884.  When the file is missing or unreadable the object stays an empty
+                   mesh, which is what the reference is left with (src/scene.cpp:218-226, :885); callers may
+                   still attach geometry to it with pt_scene_add_mesh. */
                 S->geoms.push_back(makeGeom(PT_GLTF_MESH, -1, t, r, s));
+                if (p.contains("FILE")) {
+                    std::string file = p.at("FILE").s();
+                    std::string full = file;
+                    if (file.size() > 1 && file[0] != '/' && file[1] != ':') full = dirOf(json_path) + file;
+                    std::string why;
+                    if (importGltf(S, full, t, r, s, why) < 0) S->log += "glTF object left empty: " + why + "\n";
+                }
             } else {
                 /* unknown TYPE: the reference pushes the geom with an unset type (src/scene.cpp:885) */
                 throw std::runtime_error("unknown object TYPE '" + type + "'");
@@ -421,21 +467,35 @@ int pt_scene_add_texture(PtScene* s, const uint8_t* data, int w, int h, int comp
 int pt_scene_add_mesh(PtScene* s, const PtTriangle* tris, int n, const float t[3], const float r[3], const float sc[3])
 {
     if (!s || (!tris && n > 0) || n < 0) { pt_set_error("pt_scene_add_mesh: bad argument"); return PT_EINVAL; }
-    /* fill the first still-empty glTF object with matching TRS, else append a new object */
-    int slot = -1;
-    for (size_t i = 0; i < s->geoms.size(); ++i) {
-        PtGeom& g = s->geoms[i];
-        if (g.type == PT_GLTF_MESH && g.meshIndex < 0 && !memcmp(g.translation, t, 12) && !memcmp(g.rotation, r, 12) && !memcmp(g.scale, sc, 12)) { slot = (int)i; break; }
-    }
-    if (slot < 0) { s->geoms.push_back(makeGeom(PT_GLTF_MESH, -1, t, r, sc)); slot = (int)s->geoms.size() - 1; }
-    s->meshTris.emplace_back(tris, tris + n);
-    PtMesh m; memset(&m, 0, sizeof(m));
-    s->meshes.push_back(m);
-    s->geoms[slot].meshIndex = (int)s->meshes.size() - 1;
-    s->geoms[slot].triangleCount = n;
+    int slot = attachMesh(s, std::vector<PtTriangle>(tris, tris + n), t, r, sc);
     s->refresh();
     return slot;
 }
+
+int pt_scene_import_gltf(PtScene* s, const char* path, const float t[3], const float r[3], const float sc[3])
+{
+    if (!s || !path || !t || !r || !sc) { pt_set_error("pt_scene_import_gltf: null argument"); return PT_EINVAL; }
+    std::string why;
+    int slot = importGltf(s, path, t, r, sc, why);
+    if (slot < 0) { pt_set_error("pt_scene_import_gltf: %s: %s", path, why.c_str()); return slot; }
+    s->refresh();
+    return slot;
+}
+
+int pt_decode_png(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height)
+{
+    if (!bytes || !width || !height) { pt_set_error("pt_decode_png: null argument"); return PT_EINVAL; }
+    std::vector<uint8_t> px;
+    std::string why;
+    if (!ptpng::decode(bytes, n, px, *width, *height, why)) { pt_set_error("pt_decode_png: %s", why.c_str()); return PT_EIO; }
+    if (rgba) {
+        if (capacity < px.size()) { pt_set_error("pt_decode_png: output buffer too small"); return PT_EINVAL; }
+        memcpy(rgba, px.data(), px.size());
+    }
+    return PT_OK;
+}
+
+const char* pt_scene_log(const PtScene* s) { return s ? s->log.c_str() : ""; }
 
 int pt_scene_set_envmap(PtScene* s, const float* rgb, int w, int h, float intensity)
 {

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #define PT_TRACE_MINWAVES 4
 #endif
 #ifndef PT_SHADE_MINWAVES
-#define PT_SHADE_MINWAVES 4
+#define PT_SHADE_MINWAVES 5
 #endif
 #ifndef PT_LEAF_WAIT
 #define PT_LEAF_WAIT 24

@@ -20,6 +20,7 @@
 #ifndef MI_PATHTRACE_H
 #define MI_PATHTRACE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -318,6 +319,21 @@ int pt_scene_set_depth(PtScene* s, int depth);
  * (src/scene.cpp:848-851). */
 int pt_scene_add_mesh(PtScene* s, const PtTriangle* tris, int n,
                       const float translation[3], const float rotation[3], const float scale[3]);
+/* Scene::loadGLTFModel + loadGLTFMaterial + loadGLTFTexture (src/scene.cpp:44-568): import a .glb / .gltf
+ * file as one mesh object under the TRS triple — its textures (8-bit PNG, expanded to RGBA8 as tinygltf /
+ * stb_image do for the reference) and materials are appended to the scene's tables, the triangles of every
+ * scene node are baked into world space (node "matrix" read transposed, as src/scene.cpp:286-292 does).
+ * pt_scene_load calls this for every object of TYPE "gltf" (src/scene.cpp:863-884); a file that cannot be
+ * read leaves that object empty there, as in the reference.  Returns the geom index, or PT_EIO. */
+int pt_scene_import_gltf(PtScene* s, const char* path,
+                         const float translation[3], const float rotation[3], const float scale[3]);
+/* Messages of the loader (skipped textures / primitives, unreadable glTF files), newline separated; the
+ * reference prints the like to stdout (src/scene.cpp:214-226, :337-344). */
+const char* pt_scene_log(const PtScene* s);
+/* The PNG step of the texture import on its own (role of stbi_load_from_memory with 4 requested components
+ * inside tinygltf, external/include/tiny_gltf.h): writes width*height*4 bytes when rgba is not NULL and
+ * capacity suffices; call with rgba == NULL to learn the size. */
+int pt_decode_png(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height);
 int pt_scene_add_material(PtScene* s, const PtMaterial* m);
 int pt_scene_add_texture(PtScene* s, const uint8_t* data, int w, int h, int comps);
 int pt_scene_set_envmap(PtScene* s, const float* rgb, int w, int h, float intensity);

@@ -8,6 +8,7 @@ Bars:
   * accumulated radiance vs the oracle's libm mode (the arithmetic a host build of the
     reference performs): per-channel RMSE <= RMSE_TOL of the mean radiance after SPP samples
 """
+import json
 import os
 
 import numpy as np
@@ -471,3 +472,59 @@ def test_empty_scene_and_odd_rays(pt, scenes, orc, gpu_ok, tmp_path):
     ro = np.array([[0, 4, 9], [0, 4, 9], [-5, 4, 0], [0.2, 12, 0.3], [0, 4, 0], [0, 4, 9], [1.2, 4.5, 9]], np.float32)
     rd = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 0, 0], [0, 0, -1]], np.float32)
     _hits_equal(tr.intersect(ro, rd), o.intersect(ro, rd))
+
+
+def test_scene_file_with_gltf_object_bit_exact(pt, scenes, orc, gpu_ok, tmp_path):
+    """A scene file whose mesh comes in through the glTF import (GLB with a node hierarchy, an indexed and a
+    non-indexed primitive, a PNG base-colour texture, an emissive material): closest hits and whole iterations
+    equal the oracle's on the same loaded scene, and the imported parts are really in play."""
+    import glb_util as G
+    ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    tris = scenes.blob_mesh(28, 29, 21, ident, [0, 1], radius=1.0)
+    b = G.GlbBuilder()
+    tex = b.image_png(G.write_png(scenes.checker_texture(32, 4, comps=3), 2))
+    b.material(pbrMetallicRoughness=dict(baseColorFactor=[1.0, 0.9, 0.8, 1.0], metallicFactor=0.1, roughnessFactor=0.45, baseColorTexture=dict(index=tex)))
+    b.material(pbrMetallicRoughness=dict(baseColorFactor=[0.9, 0.95, 1.0, 0.15], metallicFactor=0.0, roughnessFactor=0.05))
+    b.material(emissiveFactor=[2.0, 1.0, 0.5])
+    prims = []
+    for mid in (0, 1):
+        t = tris[tris["materialId"] == mid]
+        pos = np.stack([t["v0"], t["v1"], t["v2"]], 1).reshape(-1, 3)
+        nrm = np.stack([t["n0"], t["n1"], t["n2"]], 1).reshape(-1, 3)
+        uv = np.stack([t["uv0"], t["uv1"], t["uv2"]], 1).reshape(-1, 2)
+        if mid == 0:
+            rec = np.concatenate([pos, nrm, uv], 1)
+            uniq, inv = np.unique(rec, axis=0, return_inverse=True)
+            a_pos, a_nrm, a_uv = b.interleaved(uniq[:, 0:3], uniq[:, 3:6], uniq[:, 6:8])
+            prims.append(dict(attributes=dict(POSITION=a_pos, NORMAL=a_nrm, TEXCOORD_0=a_uv), indices=b.accessor(inv.astype(np.uint16), "SCALAR", 5123), material=0))
+        else:
+            prims.append(dict(attributes=dict(POSITION=b.accessor(pos, "VEC3", 5126), NORMAL=b.accessor(nrm, "VEC3", 5126)), material=1))
+    body = b.node(mesh=b.mesh(prims), rotation=[0.0, 0.38268343, 0.0, 0.92387953], scale=[1.2, 1.0, 1.2])
+    cube = scenes.cube_mesh(ident, 0)
+    cpos = np.stack([cube["v0"], cube["v1"], cube["v2"]], 1).reshape(-1, 3)
+    lamp = b.node(mesh=b.mesh([dict(attributes=dict(POSITION=b.accessor(cpos, "VEC3", 5126)), material=2)]), translation=[0.0, 2.0, 0.0], scale=[0.6, 0.1, 0.6])
+    b.node(root=True, children=[body, lamp], translation=[0.0, 1.2, 0.0])
+    (tmp_path / "assets").mkdir()
+    b.write_glb(tmp_path / "assets" / "blob.glb")
+    d = scenes.scene_dict("cornell_orig")
+    d["Camera"] = scenes._camera("gltf", 8, 1, res=(88, 80))
+    d["Objects"].append(dict(TYPE="gltf", FILE="assets/blob.glb", TRANS=[0.15, 1.0, 0.25], ROTAT=[0.0, 30.0, 10.0], SCALE=[1.4, 1.5, 1.4]))
+    p = tmp_path / "gltf_scene.json"
+    p.write_text(json.dumps(d))
+    sc = pt.Scene(p)
+    assert sc.log == "" and sc.geoms()[-1].triangleCount == len(tris) + 12 and len(sc.textures()) == 1
+    nm = len(sc.materials())
+    assert sc.materials()[nm - 1].type == pt.PT_EMITTING and sc.materials()[nm - 2].transparency == np.float32(1.0 - 0.15)
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    # the object transform acts on the baked triangles once more when rays are taken to object space: aim a second
+    # ray set at where the small emissive part ends up
+    M = pt.build_transforms((0.15, 1.0, 0.25), (0.0, 30.0, 10.0), (1.4, 1.5, 1.4))[0].T.astype(np.float64)
+    lamp_at = (M @ np.append(sc.mesh_triangles(0)["v0"][-12:].astype(np.float64).mean(0), 1.0))[:3]
+    sets = [_ray_set(9, 20000, center=(0.3, 5.0, 0.5), radius=4.4), _ray_set(10, 4000, center=tuple(lamp_at), radius=1.3)]
+    ro, rd = np.concatenate([s_[0] for s_ in sets]), np.concatenate([s_[1] for s_ in sets])
+    g, ob = tr.intersect(ro, rd), o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    on_mesh = g["triangle"] >= 0
+    assert on_mesh.sum() > 2000 and set(np.unique(g["materialId"][on_mesh]).tolist()) == {nm - 3, nm - 2, nm - 1}
+    _assert_full_parity(pt, orc, sc, [1, 2, 3])
