@@ -145,6 +145,10 @@ def _load():
         "pt_scene_import_gltf": (ip, [vp, C.c_char_p, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
         "pt_scene_log": (C.c_char_p, [vp]),
         "pt_decode_png": (ip, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "pt_image_to_rgb8": (ip, [vp, ip, ip, fp, vp]),
+        "pt_image_average": (ip, [vp, ip, ip, fp, ip, vp]),
+        "pt_write_png": (ip, [C.c_char_p, vp, ip, ip, ip]),
+        "pt_write_hdr": (ip, [C.c_char_p, vp, ip, ip]),
         "pt_scene_add_material": (ip, [vp, C.POINTER(PtMaterial)]),
         "pt_scene_add_texture": (ip, [vp, vp, ip, ip, ip]),
         "pt_scene_set_envmap": (ip, [vp, vp, ip, ip, fp]),
@@ -225,6 +229,35 @@ def decode_png(data):
     out = np.empty((h.value, w.value, 4), np.uint8)
     _check(lib.pt_decode_png(buf.ctypes.data, len(buf), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)), "pt_decode_png")
     return out
+
+
+def image_to_rgb8(image_sum, samples):
+    """Running sum (H, W, 3) -> the 8-bit image the reference saves: x mirrored, averaged, clamped, truncated."""
+    a = np.ascontiguousarray(image_sum, np.float32)
+    h, w = a.shape[:2]
+    out = np.empty((h, w, 3), np.uint8)
+    _check(lib.pt_image_to_rgb8(a.ctypes.data, w, h, float(samples), out.ctypes.data), "pt_image_to_rgb8")
+    return out
+
+
+def image_average(image_sum, samples, mirror_x=True):
+    a = np.ascontiguousarray(image_sum, np.float32)
+    h, w = a.shape[:2]
+    out = np.empty((h, w, 3), np.float32)
+    _check(lib.pt_image_average(a.ctypes.data, w, h, float(samples), int(mirror_x), out.ctypes.data), "pt_image_average")
+    return out
+
+
+def write_png(path, pixels):
+    a = np.ascontiguousarray(pixels, np.uint8)
+    h, w = a.shape[:2]
+    _check(lib.pt_write_png(os.fspath(path).encode(), a.ctypes.data, w, h, 1 if a.ndim == 2 else a.shape[2]), "pt_write_png")
+
+
+def write_hdr(path, rgb):
+    a = np.ascontiguousarray(rgb, np.float32)
+    h, w = a.shape[:2]
+    _check(lib.pt_write_hdr(os.fspath(path).encode(), a.ctypes.data, w, h), "pt_write_hdr")
 
 
 class Scene:

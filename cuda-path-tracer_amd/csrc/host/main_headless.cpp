@@ -3,11 +3,13 @@
  * pathtraceInit once, pathtrace(nullptr, 0, iteration) for iteration = 1..N exactly as runCuda does
  * (src/main.cpp:812-837), write the image.
  *
- *   pt_headless scene.json [-n iterations] [-r W H] [-d depth] [-o out.pfm|out.ppm] [--batch]
+ *   pt_headless scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch]
  *
- * .pfm holds the running sum divided by the iteration count (float RGB, bottom row first as the
- * format demands); .ppm the 8-bit image saveImage() produces: samples averaged, clamped to [0,1],
- * x mirrored (src/main.cpp:351-375, src/image.cpp:23-50).
+ * .png / .ppm hold the 8-bit image saveImage() + Image::savePNG produce (samples averaged, x mirrored,
+ * clamped to [0,1]; src/main.cpp:351-375, src/image.cpp:23-43), .hdr the Radiance file of Image::saveHDR
+ * (src/image.cpp:45-50), .pfm the unmirrored float average (bottom row first as the format demands).
+ * Without -o the image goes to <FILE of the camera block>.<iterations>samp.png, the reference's naming
+ * without its start-time part.
  */
 #include "pathtrace.h"
 
@@ -25,7 +27,7 @@ static bool endsWith(const std::string& s, const char* suf)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s scene.json [-n iterations] [-r W H] [-d depth] [-o out.pfm|out.ppm] [--batch]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch]\n", argv[0]); return 2; }
     int iterations = -1, W = 0, H = 0, depth = 0;
     bool batch = false;
     std::string out;
@@ -39,10 +41,11 @@ int main(int argc, char** argv)
     }
     Scene* scene = nullptr;
     if (pt_scene_load(argv[1], &scene) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
+    if (*pt_scene_log(scene)) fputs(pt_scene_log(scene), stderr);
     if (W > 0 && H > 0 && pt_scene_set_resolution(scene, W, H) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
     if (depth > 0 && pt_scene_set_depth(scene, depth) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
     if (iterations < 0) iterations = pt_scene_iterations(scene);
-    if (out.empty()) out = std::string(pt_scene_image_name(scene)) + ".pfm";
+    if (out.empty()) out = std::string(pt_scene_image_name(scene)) + "." + std::to_string(iterations) + "samp.png";
 
     GuiDataContainer gui;
     InitDataContainer(&gui);
@@ -60,32 +63,36 @@ int main(int argc, char** argv)
     const PtSceneDesc* d = pt_scene_desc(scene);
     const int w = d->camera.resolution[0], h = d->camera.resolution[1];
     const float* img = pt_scene_image(scene);
-    FILE* f = fopen(out.c_str(), "wb");
-    if (!f) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
-    const float inv = iterations > 0 ? 1.0f / (float)iterations : 1.0f;
-    if (endsWith(out, ".ppm")) {
-        fprintf(f, "P6\n%d %d\n255\n", w, h);
-        std::vector<unsigned char> row(3 * (size_t)w);
-        for (int y = 0; y < h; ++y) {
-            for (int x = 0; x < w; ++x) {
-                const float* p = img + 3 * ((size_t)y * w + x);
-                for (int k = 0; k < 3; ++k) {
-                    float v = p[k] * inv;
-                    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                    row[3 * (size_t)(w - 1 - x) + k] = (unsigned char)(v * 255.0f);
-                }
-            }
-            fwrite(row.data(), 1, row.size(), f);
+    const float samples = (float)(iterations > 0 ? iterations : 1);
+    int rc = PT_OK;
+    if (endsWith(out, ".png") || endsWith(out, ".ppm")) {
+        /* what saveImage() + Image::savePNG produce: averaged, x mirrored, clamped, 8 bit */
+        std::vector<unsigned char> rgb(3 * (size_t)w * h);
+        rc = pt_image_to_rgb8(img, w, h, samples, rgb.data());
+        if (rc == PT_OK && endsWith(out, ".png")) rc = pt_write_png(out.c_str(), rgb.data(), w, h, 3);
+        else if (rc == PT_OK) {
+            FILE* f = fopen(out.c_str(), "wb");
+            if (!f) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+            fprintf(f, "P6\n%d %d\n255\n", w, h);
+            fwrite(rgb.data(), 1, rgb.size(), f);
+            fclose(f);
         }
+    } else if (endsWith(out, ".hdr")) {
+        /* what saveImage() + Image::saveHDR produce */
+        std::vector<float> avg(3 * (size_t)w * h);
+        rc = pt_image_average(img, w, h, samples, 1, avg.data());
+        if (rc == PT_OK) rc = pt_write_hdr(out.c_str(), avg.data(), w, h);
     } else {
+        /* .pfm: the unmirrored average, for numeric comparison */
+        std::vector<float> avg(3 * (size_t)w * h);
+        rc = pt_image_average(img, w, h, samples, 0, avg.data());
+        FILE* f = fopen(out.c_str(), "wb");
+        if (!f) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
         fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
-        std::vector<float> row(3 * (size_t)w);
-        for (int y = h - 1; y >= 0; --y) {
-            for (size_t i = 0; i < row.size(); ++i) row[i] = img[3 * (size_t)y * w + i] * inv;
-            fwrite(row.data(), sizeof(float), row.size(), f);
-        }
+        for (int y = h - 1; y >= 0; --y) fwrite(avg.data() + 3 * (size_t)y * w, sizeof(float), 3 * (size_t)w, f);
+        fclose(f);
     }
-    fclose(f);
+    if (rc != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
     printf("%s: %d iterations, %dx%d, traced depth %d -> %s\n", argv[1], iterations, w, h, gui.TracedDepth, out.c_str());
     pathtraceFree();
     pt_scene_free(scene);

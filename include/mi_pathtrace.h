@@ -345,6 +345,17 @@ float* pt_scene_image(PtScene* s);
 int pt_scene_iterations(const PtScene* s);
 const char* pt_scene_image_name(const PtScene* s);
 
+/* Output side (role of saveImage, src/main.cpp:351-375, and Image::savePNG / saveHDR, src/image.cpp:23-50).
+ * sum is the W*H*3 running sum (pt_download / pt_scene_image), samples the iteration count.
+ *   pt_image_to_rgb8   x mirrored, sum / samples, clamp to [0,1], * 255, truncated: the bytes savePNG encodes
+ *   pt_image_average   sum / samples as floats (mirror_x != 0: mirrored as saveImage does), what saveHDR encodes
+ *   pt_write_png       8-bit grey / RGB / RGBA file (components 1, 3, 4)
+ *   pt_write_hdr       Radiance RGBE file; float -> RGBE as stb_image_write does (stb_image_write.h:639-657) */
+int pt_image_to_rgb8(const float* sum, int width, int height, float samples, uint8_t* rgb);
+int pt_image_average(const float* sum, int width, int height, float samples, int mirror_x, float* out);
+int pt_write_png(const char* path, const uint8_t* pixels, int width, int height, int components);
+int pt_write_hdr(const char* path, const float* rgb, int width, int height);
+
 /* utilityCore::buildTransformationMatrix + glm::inverse + glm::inverseTranspose
  * (src/utilities.cpp:85-93, src/scene.cpp:848-851) for one TRS triple. */
 void pt_build_transforms(const float translation[3], const float rotation[3], const float scale[3],

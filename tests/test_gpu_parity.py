@@ -8,6 +8,7 @@ Bars:
   * accumulated radiance vs the oracle's libm mode (the arithmetic a host build of the
     reference performs): per-channel RMSE <= RMSE_TOL of the mean radiance after SPP samples
 """
+import ctypes as C
 import json
 import os
 
@@ -375,7 +376,8 @@ def test_pathtrace_surface_headless_driver(pt, scenes, orc, gpu_ok, tmp_path):
     o = orc.Oracle(pt, sc, orc.MATH_DET)
     for it in range(1, n + 1):
         o.trace(it)
-    expect = (o.image().reshape(H, W, 3) * (np.float32(1.0) / np.float32(n))).astype(np.float32)
+    total = o.image().reshape(H, W, 3)
+    expect = (total / np.float32(n)).astype(np.float32)
     o.close()
     for extra in ([], ["--batch"]):
         out = str(tmp_path / ("img%d.pfm" % len(extra)))
@@ -387,6 +389,22 @@ def test_pathtrace_surface_headless_driver(pt, scenes, orc, gpu_ok, tmp_path):
             got = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
         assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
         assert got.sum() > 0
+    # the reference's own output forms: 8-bit PNG (averaged, x mirrored, clamped, truncated) and Radiance .hdr
+    png, hdr = str(tmp_path / "img.png"), str(tmp_path / "img.hdr")
+    subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", png], timeout=120)
+    subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", hdr, "--batch"], timeout=120)
+    want8 = (np.clip(expect[:, ::-1], 0, 1) * np.float32(255)).astype(np.uint8)
+    got8 = pt.decode_png(open(png, "rb").read())
+    assert np.array_equal(got8[:, :, :3], want8) and (got8[:, :, 3] == 255).all()
+    env = json.load(open(path))
+    env["EnvironmentMap"] = dict(FILE="img.hdr", INTENSITY=1.0)
+    (tmp_path / "env.json").write_text(json.dumps(env))
+    sc2 = pt.Scene(tmp_path / "env.json")
+    back = sc2.desc.contents.env
+    assert (back.width, back.height, back.enabled) == (W, H, 1)
+    rgbe = np.frombuffer(C.string_at(back.data, W * H * 12), np.float32).reshape(H, W, 3)
+    m = expect[:, ::-1].max(axis=2, keepdims=True)
+    assert np.all(np.abs(rgbe - expect[:, ::-1]) <= m / 128 + 1e-30)       # 8-bit mantissa shared by the three channels
 
 
 def test_full_size_properties_dragon_1080p(pt, scenes, gpu_ok):
