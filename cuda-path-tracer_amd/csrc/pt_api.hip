@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,10 +26,10 @@ void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt
 void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount);
 void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
                uint32_t* fetchCtr, const uint32_t* workCount, void* dc);
-void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc);
+void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc, bool sparse);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-               uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc);
+               uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc, bool sparse);
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride);
@@ -77,6 +78,14 @@ struct PtContext {
     hipStream_t shadowStreams[kMaxStreamGroups] = {};
     hipEvent_t shadedEvents[kMaxStreamGroups] = {}, shadowDoneEvents[kMaxStreamGroups] = {};
     int shadowOverlap = 1;
+    /* Live-path maxima per bounce of the last finished launch group, copied to pinned memory behind every group.
+     * They only choose the launch form of the heavy per-slot kernels for the next group (nearly empty bounces take
+     * the bounded grid); either form is correct for any count. */
+    uint32_t* liveHintHost = nullptr;   /* pinned */
+    hipEvent_t hintEvent = nullptr;
+    bool hintPending = false, hintValid = false;
+    uint32_t liveHint[PT_MAX_DEPTH + 2] = {};
+    int sparseMode = -1;                /* PT_SPARSE: -1 by hint, 0 never, 1 always (testing) */
     int rowsPerGroup = 32;              /* a stream group is worth it from this many iterations on */
     PtCamera cam{};
     int traceDepth = 8;
@@ -678,6 +687,8 @@ int pt_destroy(PtContext* c)
         if (c->shadowDoneEvents[g]) (void)hipEventDestroy(c->shadowDoneEvents[g]);
     }
     if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
+    if (c->hintEvent) (void)hipEventDestroy(c->hintEvent);
+    if (c->liveHintHost) (void)hipHostFree(c->liveHintHost);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -721,6 +732,9 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
 #define TRY_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { pt_set_error("%s failed: %s", #x, hipGetErrorString(e_)); pt_destroy(c); return PT_EHIP; } } while (0)
     TRY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TRY_HIP(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&c->hintEvent, hipEventDisableTiming));
+    TRY_HIP(hipHostMalloc((void**)&c->liveHintHost, sizeof(uint32_t) * (PT_MAX_DEPTH + 2), hipHostMallocDefault));
+    { const char* e = getenv("PT_SPARSE"); if (e) c->sparseMode = atoi(e); }
     for (int g = 0; g < kMaxStreamGroups; ++g) {
         TRY_HIP(hipStreamCreateWithFlags(&c->groupStreams[g], hipStreamNonBlocking));
         TRY_HIP(hipEventCreateWithFlags(&c->joinEvents[g], hipEventDisableTiming));
@@ -883,6 +897,13 @@ static int traceBatch(PtContext* c, Batch bt)
     uint32_t* shadowCount = ctr + 2 * kWorkCtrSection;
     uint32_t* closestCount = ctr + 3 * kWorkCtrSection;
     const bool meshes = V.numBvhMeshes > 0;
+    if (c->hintPending && hipEventQuery(c->hintEvent) == hipSuccess) {
+        memcpy(c->liveHint, c->liveHintHost, sizeof(c->liveHint));
+        c->hintPending = false;
+        c->hintValid = true;
+    }
+    const uint32_t sparseBelow = (uint32_t)c->numPixels / 16u;
+    auto sparseBounce = [&](int b) { return c->sparseMode >= 0 ? c->sparseMode != 0 : (c->hintValid && c->liveHint[b] <= sparseBelow); };
     /* The rows of a launch group are independent until the final accumulation, so they can be spread over
      * several streams: while one group's traversal kernel drains its last long rays, the kernels of the
      * other groups fill the machine.  With stage timing on everything stays on one stream so that the
@@ -913,14 +934,14 @@ static int traceBatch(PtContext* c, Batch bt)
                     SpanGuard t(c, ST_TRACE, gs);
                     ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + row, closestCount + row, c->dc);
                 }
-                ptl_prims(gs, V, st, q, gb, b, c->sortOn, count, c->dc);
+                ptl_prims(gs, V, st, q, gb, b, c->sortOn, count, c->dc, sparseBounce(b));
             }
             if (c->sortOn) { SpanGuard sg(c, ST_SORT, gs); ptl_sort(gs, q, gb, b, V.numBuckets); }
             {
                 if (shadowOpen) { HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[g], 0)); shadowOpen = false; }
                 SpanGuard sg(c, ST_SHADE, gs);
                 ptl_shade(gs, V, st, q, gb, b, c->sortOn, count, shadowCount + row,
-                          (meshes && b + 1 < c->traceDepth) ? closestCount + row + (size_t)kMaxBatch * kCtrStride : nullptr, c->dc);
+                          (meshes && b + 1 < c->traceDepth) ? closestCount + row + (size_t)kMaxBatch * kCtrStride : nullptr, c->dc, sparseBounce(b));
                 if (meshes) {
                     if (side) { HIP_TRY(hipEventRecord(c->shadedEvents[g], gs)); HIP_TRY(hipStreamWaitEvent(ss, c->shadedEvents[g], 0)); }
                     SpanGuard t(c, ST_SHADOW_TRACE, ss);
@@ -937,6 +958,11 @@ static int traceBatch(PtContext* c, Batch bt)
         }
     }
     ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc, shadowCount, closestCount, kMaxBatch);
+    if (!c->hintPending) {
+        HIP_TRY(hipMemcpyAsync(c->liveHintHost, (const char*)c->dc + offsetof(DevCounters, liveMax), sizeof(c->liveHint), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->hintEvent, s));
+        c->hintPending = true;
+    }
     HIP_TRY(hipGetLastError());
     c->iterations += (uint64_t)bt.count;
     return PT_OK;
@@ -1114,7 +1140,7 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
                 ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection);
                 ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, ctr, ctr + 3 * kWorkCtrSection, nullptr);
             }
-            ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr);
+            ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr, false);
             ptl_export_hits(c->stream, c->state, m, dH);
             e = hipGetLastError();
         }

@@ -54,8 +54,9 @@ PT_DEV int blockAppendIndex(bool flag, uint32_t* counter, int* s_tmp)
  * is bounded by the machine, not by the image: a workgroup walks "virtual" workgroups vb = blockIdx.x,
  * blockIdx.x + gridDim.x, ... while they hold live slots.  Late bounces have few live paths; a grid sized for
  * the whole image would spend its time launching workgroups that exit at once (a quarter of a million per
- * kernel for 32 iterations at 1080p, about 55 us).  The heavy kernels (k_prims, k_shade) keep one workgroup
- * per 256 slots: wrapped in such a loop they lose more than the launches cost. */
+ * kernel for 32 iterations at 1080p, about 55 us).  The heavy kernels (k_prims, k_shade) come in two forms: one
+ * workgroup per 256 slots (on a bounded grid a crowded bounce loses more than the launches cost), and a SPARSE
+ * form on a bounded grid that the host picks for bounces it knows to be nearly empty. */
 #define PT_FOR_VIRTUAL_BLOCKS(vb, n) for (int vb = (int)blockIdx.x; (uint32_t)(vb * kBlock) < (n); vb += (int)gridDim.x)
 
 PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
@@ -341,8 +342,11 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     }
 }
 
-/* fold the inline geoms into the mesh result; final hit record, sort bucket, bucket histogram */
-template <bool COUNT>
+/* fold the inline geoms into the mesh result; final hit record, sort bucket, bucket histogram.
+ * SPARSE: the grid is bounded and a workgroup walks the 256-slot pieces vb, vb + gridDim.x, ... of its row — for
+ * bounces whose rows are known to be nearly empty, where one workgroup per 256 slots of the full image is mostly
+ * launch overhead.  Both forms give every piece the same treatment. */
+template <bool COUNT, bool SPARSE>
 __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Queues q, int bounce, int sortOn, DevCounters* dc)
 {
     __shared__ int s_hist[kMaxBuckets];
@@ -350,52 +354,59 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
     q = q.at(blockIdx.y);
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
-    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
-    const int slot = blockIdx.x * kBlock + tid;
+    int vb = (int)blockIdx.x;
+    if ((uint32_t)(vb * kBlock) >= n) return;
     const int numBuckets = S.numBuckets;
-    if (sortOn) {
-        for (int i = tid; i < numBuckets; i += kBlock) s_hist[i] = 0;
-        __syncthreads();
-    }
-    const bool active = (uint32_t)slot < n;
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
-    int key = 0;
-    if (active) {
-        const int pix = bounce == 0 ? slot : q.q0[slot];
-        float4 o = st.rayO[pix], d = st.rayD[pix];
-        Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
-        Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
-        if (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0) {      /* the ray was filed for traversal */
-            float4 ha = st.hitA[pix], hb = st.hitB[pix];
-            best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
-            best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
-            best.tri = st.hitTri[pix];
+    do {
+        const int slot = vb * kBlock + tid;
+        if (sortOn) {
+            for (int i = tid; i < numBuckets; i += kBlock) s_hist[i] = 0;
+            __syncthreads();
         }
-        const bool traced = best.geom >= 0 || (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0);
-        const int meshGeom = best.geom;
-        foldInlineGeoms<COUNT>(S, r, best, cnt);
-        if (!traced || best.geom != meshGeom) {       /* the traversal's record stands unless an inline geom is closer */
-            st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
-            st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
-            st.hitTri[pix] = best.tri;
+        const bool active = (uint32_t)slot < n;
+        int key = 0;
+        if (active) {
+            const int pix = bounce == 0 ? slot : q.q0[slot];
+            float4 o = st.rayO[pix], d = st.rayD[pix];
+            Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+            Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
+            if (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0) {      /* the ray was filed for traversal */
+                float4 ha = st.hitA[pix], hb = st.hitB[pix];
+                best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
+                best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
+                best.tri = st.hitTri[pix];
+            }
+            const bool traced = best.geom >= 0 || (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0);
+            const int meshGeom = best.geom;
+            foldInlineGeoms<COUNT>(S, r, best, cnt);
+            if (!traced || best.geom != meshGeom) {       /* the traversal's record stands unless an inline geom is closer */
+                st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
+                st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
+                st.hitTri[pix] = best.tri;
+            }
+            /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */
+            key = (best.t > 0.0f) ? best.mat : (numBuckets - 1);
+            if (sortOn) q.keys[slot] = key;
         }
-        /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */
-        key = (best.t > 0.0f) ? best.mat : (numBuckets - 1);
-        if (sortOn) q.keys[slot] = key;
-    }
+        if (sortOn) {
+            /* wave-aggregated: one LDS atomic per distinct bucket per wave */
+            unsigned long long todo = __ballot(active);
+            while (todo) {
+                int leader = __builtin_ctzll(todo);
+                int k = __shfl(key, leader);
+                unsigned long long m = __ballot(active && key == k);
+                if (laneId() == leader) atomicAdd(&s_hist[k], (int)__builtin_popcountll(m));
+                todo &= ~m;
+            }
+            __syncthreads();
+            for (int i = tid; i < numBuckets; i += kBlock) q.blockHist[(size_t)i * q.numBlocks + vb] = s_hist[i];
+        }
+        if (!SPARSE) break;
+        vb += (int)gridDim.x;
+        __syncthreads();
+    } while ((uint32_t)(vb * kBlock) < n);
     if (COUNT) flushCounters(cnt, dc, 0);
-    if (!sortOn) return;
-    /* wave-aggregated: one LDS atomic per distinct bucket per wave */
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        int leader = __builtin_ctzll(todo);
-        int k = __shfl(key, leader);
-        unsigned long long m = __ballot(active && key == k);
-        if (laneId() == leader) atomicAdd(&s_hist[k], (int)__builtin_popcountll(m));
-        todo &= ~m;
-    }
-    __syncthreads();
-    for (int i = tid; i < numBuckets; i += kBlock) q.blockHist[(size_t)i * q.numBlocks + blockIdx.x] = s_hist[i];
 }
 
 /* block-wide exclusive scan helper for 1024 threads; returns the exclusive prefix of v and the
@@ -507,7 +518,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(Queues q, int bounce, i
  * meshes exist and nothing inline blocks, the ray goes to the shadow queue with the path colour of
  * the unblocked outcome, and the path itself continues with the blocked outcome until k_trace in
  * shadow mode settles it (before the next stage reads the colour). */
-template <bool COUNT>
+template <bool COUNT, bool SPARSE>
 __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S, PathState st, Queues q, Batch bt, int bounce, int sortOn,
                                                                      uint32_t* shadowCount, uint32_t* nextTraceCount, DevCounters* dc)
 {
@@ -518,64 +529,70 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
     const int tid = threadIdx.x;
     const uint32_t n = q.live[bounce];
-    if ((uint32_t)(blockIdx.x * kBlock) >= n) return;
-    const int slot = blockIdx.x * kBlock + tid;
-    const bool active = (uint32_t)slot < n;
+    int vb = (int)blockIdx.x;                   /* SPARSE: bounded grid, see k_prims */
+    if ((uint32_t)(vb * kBlock) >= n) return;
     int* queue = sortOn ? q.q1 : q.q0;
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
-    bool alive = false;
-    ShadowReq sq;
-    sq.pending = false; sq.o = f3(0.0f); sq.d = f3(0.0f); sq.dist = 0.0f; sq.lightGeom = -1; sq.colorVisible = f3(0.0f);
-    int pix = 0;
-    bool cand = false;
-    if (active) {
-        pix = (!sortOn && bounce == 0) ? slot : queue[slot];
-        float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
-        float4 ha = st.hitA[pix], hb = st.hitB[pix];
-        Path p;
-        p.o = f3(o.x, o.y, o.z); p.d = f3(d.x, d.y, d.z); p.color = f3(c.x, c.y, c.z);
-        p.remaining = __float_as_int(c.w);
-        p.prevSpecular = __float_as_int(o.w) != 0;
-        F2 uv; uv.x = hb.y; uv.y = hb.z;
-        shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0, sq, cnt);
-        alive = p.remaining > 0;
-        if (alive) {
-            /* the surviving path's new ray goes on the work list of the next closest-hit traversal if it can hit a mesh */
-            if (nextTraceCount) { Ray nr; nr.o = p.o; nr.d = p.d; cand = mayHitBvhMeshes(S, nr, __builtin_inff()); }
-            st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
-            st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(cand ? 1 : 0));
+    do {
+        const int slot = vb * kBlock + tid;
+        const bool active = (uint32_t)slot < n;
+        bool alive = false;
+        ShadowReq sq;
+        sq.pending = false; sq.o = f3(0.0f); sq.d = f3(0.0f); sq.dist = 0.0f; sq.lightGeom = -1; sq.colorVisible = f3(0.0f);
+        int pix = 0;
+        bool cand = false;
+        if (active) {
+            pix = (!sortOn && bounce == 0) ? slot : queue[slot];
+            float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
+            float4 ha = st.hitA[pix], hb = st.hitB[pix];
+            Path p;
+            p.o = f3(o.x, o.y, o.z); p.d = f3(d.x, d.y, d.z); p.color = f3(c.x, c.y, c.z);
+            p.remaining = __float_as_int(c.w);
+            p.prevSpecular = __float_as_int(o.w) != 0;
+            F2 uv; uv.x = hb.y; uv.y = hb.z;
+            shadeSlot<COUNT>(S, iter, bounce + 1, slot, p, ha.x, f3(ha.y, ha.z, ha.w), __float_as_int(hb.x), uv, bounce == 0, sq, cnt);
+            alive = p.remaining > 0;
+            if (alive) {
+                /* the surviving path's new ray goes on the work list of the next closest-hit traversal if it can hit a mesh */
+                if (nextTraceCount) { Ray nr; nr.o = p.o; nr.d = p.d; cand = mayHitBvhMeshes(S, nr, __builtin_inff()); }
+                st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
+                st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(cand ? 1 : 0));
+            }
+            if (alive || sq.pending) {
+                st.col[pix] = make_float4(p.color.x, p.color.y, p.color.z, __int_as_float(p.remaining));
+            } else if (p.remaining == 0) {
+                /* gatherTerminatedPaths (src/pathtrace.cu:2641-2653): one path per pixel, so a plain add */
+                float* im = st.image + 3 * (size_t)pix;
+                im[0] += p.color.x; im[1] += p.color.y; im[2] += p.color.z;
+            }
+            queue[slot] = alive ? pix : (-1 - pix);
         }
-        if (alive || sq.pending) {
-            st.col[pix] = make_float4(p.color.x, p.color.y, p.color.z, __int_as_float(p.remaining));
-        } else if (p.remaining == 0) {
-            /* gatherTerminatedPaths (src/pathtrace.cu:2641-2653): one path per pixel, so a plain add */
-            float* im = st.image + 3 * (size_t)pix;
-            im[0] += p.color.x; im[1] += p.color.y; im[2] += p.color.z;
+        if (nextTraceCount) {
+            const int at = blockAppendIndex(cand, nextTraceCount + blockIdx.y * kCtrStride, s_tmp);
+            if (at >= 0) st.traceQueue[at] = pix;
         }
-        queue[slot] = alive ? pix : (-1 - pix);
-    }
-    if (nextTraceCount) {
-        const int at = blockAppendIndex(cand, nextTraceCount + blockIdx.y * kCtrStride, s_tmp);
-        if (at >= 0) st.traceQueue[at] = pix;
-    }
-    /* shadow queue append */
-    const int shIdx = blockAppendIndex(sq.pending, shadowCount + blockIdx.y * kCtrStride, s_tmp);
-    if (shIdx >= 0) {
-        st.workQueue[shIdx] = pix;
-        st.shO[pix] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
-        st.shD[pix] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
-        st.shC[pix] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, 0.0f);
-    }
-    if (COUNT) flushCounters(cnt, dc, 1);
-    unsigned long long m = __ballot(alive);
-    if (laneId() == 0) s_alive[tid >> 6] = (int)__builtin_popcountll(m);
-    __syncthreads();
-    if (tid == 0) {
-        int s = 0;
+        /* shadow queue append */
+        const int shIdx = blockAppendIndex(sq.pending, shadowCount + blockIdx.y * kCtrStride, s_tmp);
+        if (shIdx >= 0) {
+            st.workQueue[shIdx] = pix;
+            st.shO[pix] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
+            st.shD[pix] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
+            st.shC[pix] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, 0.0f);
+        }
+        unsigned long long m = __ballot(alive);
+        if (laneId() == 0) s_alive[tid >> 6] = (int)__builtin_popcountll(m);
+        __syncthreads();
+        if (tid == 0) {
+            int s = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += s_alive[w];
-        q.blockAlive[blockIdx.x] = s;
-    }
+            for (int w = 0; w < kBlock / 64; ++w) s += s_alive[w];
+            q.blockAlive[vb] = s;
+        }
+        if (!SPARSE) break;
+        vb += (int)gridDim.x;
+        __syncthreads();
+    } while ((uint32_t)(vb * kBlock) < n);
+    if (COUNT) flushCounters(cnt, dc, 1);
 }
 
 /* exclusive scan of survivors per workgroup; publishes live[bounce + 1] */
@@ -667,6 +684,10 @@ __global__ void k_finish(Queues q0, int depth, int batch, DevCounters* dc, const
             uint32_t v = q.live[b];
             s += v;
             if (v == 0) break;
+        }
+        for (int b = 0; b <= depth; ++b) {
+            uint32_t v = q.live[b];
+            if (k == 0 || v > dc->liveMax[b]) dc->liveMax[b] = v;
         }
         if (k == batch - 1)
             for (int b = 0; b <= depth; ++b) dc->lastLive[b] = q.live[b];
@@ -803,10 +824,20 @@ void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch 
         else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
     }
 }
-void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc)
+/* grid of the SPARSE form of the heavy per-slot kernels: about 4096 workgroups over all rows */
+static inline dim3 sparseGrid(const Queues& q, const Batch& bt)
 {
-    if (count) hipLaunchKernelGGL(k_prims<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_prims<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    int x = (4096 + bt.count - 1) / bt.count;
+    if (x > q.numBlocks) x = q.numBlocks;
+    if (x < 1) x = 1;
+    return dim3(x, bt.count);
+}
+void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc, bool sparse)
+{
+    const dim3 full(q.numBlocks, bt.count);
+    if (count) hipLaunchKernelGGL((k_prims<true, false>), full, dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    else if (sparse) hipLaunchKernelGGL((k_prims<false, true>), sparseGrid(q, bt), dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
+    else hipLaunchKernelGGL((k_prims<false, false>), full, dim3(kBlock), 0, s, S, st, q, bounce, sortOn, (DevCounters*)dc);
 }
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
 {
@@ -814,10 +845,12 @@ void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets)
     hipLaunchKernelGGL(k_sort_scatter, slotGrid(q, bt), dim3(kBlock), 0, s, q, bounce, numBuckets);
 }
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
-               uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc)
+               uint32_t* shadowCount, uint32_t* nextTraceCount, void* dc, bool sparse)
 {
-    if (count) hipLaunchKernelGGL(k_shade<true>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
+    const dim3 full(q.numBlocks, bt.count);
+    if (count) hipLaunchKernelGGL((k_shade<true, false>), full, dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
+    else if (sparse) hipLaunchKernelGGL((k_shade<false, true>), sparseGrid(q, bt), dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
+    else hipLaunchKernelGGL((k_shade<false, false>), full, dim3(kBlock), 0, s, S, st, q, bt, bounce, sortOn, shadowCount, nextTraceCount, (DevCounters*)dc);
 }
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
 {

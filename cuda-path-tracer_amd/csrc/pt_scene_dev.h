@@ -134,6 +134,7 @@ struct DevCounters {
     unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
     unsigned long long waveDiag[2][6];  /* per traversal mode: wave iterations, node-step lanes, leaf-step lanes, held-leaf lanes, refills, refilled lanes */
     uint32_t lastLive[PT_MAX_DEPTH + 2];
+    uint32_t liveMax[PT_MAX_DEPTH + 2]; /* per bounce, the largest live count over the rows of the last launch group */
 };
 
 struct TravCounters { uint32_t nodes, tris, meshHits, boxes; };

@@ -546,3 +546,28 @@ def test_scene_file_with_gltf_object_bit_exact(pt, scenes, orc, gpu_ok, tmp_path
     on_mesh = g["triangle"] >= 0
     assert on_mesh.sum() > 2000 and set(np.unique(g["materialId"][on_mesh]).tolist()) == {nm - 3, nm - 2, nm - 1}
     _assert_full_parity(pt, orc, sc, [1, 2, 3])
+
+
+def test_sparse_launch_form_is_bit_identical(pt, scenes, orc, gpu_ok, monkeypatch):
+    """The heavy per-slot kernels have a bounded-grid form for nearly empty bounces, picked from the previous launch
+    group's live counts; forced on for every bounce (PT_SPARSE=1), forced off, or picked by the hint over several
+    groups, the image is the same and equals the oracle's."""
+    sc = scenes.make_scene("dragon", res=(160, 90), depth=8, grid=(48, 49), env_size=(64, 32), tex_size=16)
+    images = []
+    for mode in ("1", "0", None):
+        if mode is None:
+            monkeypatch.delenv("PT_SPARSE", raising=False)
+        else:
+            monkeypatch.setenv("PT_SPARSE", mode)
+        tr = pt.Tracer(sc)
+        tr.set_option(pt.PT_OPT_BATCH, 4)
+        for first in (1, 5, 9):                 # three launch groups: the second and third may use the hint of the one before
+            tr.trace_range(first, first + 4, 1)
+            tr.sync()
+        images.append(tr.image())
+        del tr
+    assert _same_bits(images[0], images[1]) and _same_bits(images[0], images[2])
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    for it in range(1, 13):
+        o.trace(it)
+    assert _same_bits(images[0], o.image())
