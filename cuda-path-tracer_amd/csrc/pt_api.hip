@@ -52,6 +52,8 @@ constexpr int kDefaultStreamGroups = 3;
 constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
 constexpr int kMaxBatch = 256;
 constexpr int kMaxStreamGroups = 8;
+constexpr int kTuneShapes = 3;          /* launch shapes tried: 1, 2, 3 streams */
+constexpr int kTuneMinRows = 12;        /* smaller launch groups stay on one stream */
 /* device work counters, zeroed before every launch group: [section][bounce][batch row] with sections
  * 0 = next entry of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length,
  * 3 = closest-hit work queue length */
@@ -86,7 +88,17 @@ struct PtContext {
     bool hintPending = false, hintValid = false;
     uint32_t liveHint[PT_MAX_DEPTH + 2] = {};
     int sparseMode = -1;                /* PT_SPARSE: -1 by hint, 0 never, 1 always (testing) */
-    int rowsPerGroup = 32;              /* a stream group is worth it from this many iterations on */
+    int rowsPerGroup = 32;              /* a stream group is worth it from this many iterations on (fixed stream count only) */
+    /* Launch-shape choice.  Whether the rows of a launch group run best on one stream (shadow traversal beside the
+     * next closest-hit stage) or spread over two or three depends on the scene: with a cache-resident BVH one stream
+     * reaches the sum of the stage times and more streams only disturb each other, with a multi-million-triangle
+     * mesh the overlap is worth 20 %.  So the first launch groups of a given size try the shapes in turn (GPU time
+     * between two events on the main stream, one blocking wait each) and the rest use the fastest.  PT_STREAMS fixes
+     * the shape instead.  Results do not depend on the shape. */
+    bool streamsFixed = false;
+    int tuneRows = -1, tuneStage = 0, tuneChoice = 1;
+    float tuneMs[kMaxStreamGroups + 1] = {};
+    hipEvent_t tuneStart = nullptr, tuneEnd = nullptr;
     PtCamera cam{};
     int traceDepth = 8;
     int numPixels = 0;
@@ -688,6 +700,8 @@ int pt_destroy(PtContext* c)
     }
     if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
     if (c->hintEvent) (void)hipEventDestroy(c->hintEvent);
+    if (c->tuneStart) (void)hipEventDestroy(c->tuneStart);
+    if (c->tuneEnd) (void)hipEventDestroy(c->tuneEnd);
     if (c->liveHintHost) (void)hipHostFree(c->liveHintHost);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -733,6 +747,8 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     TRY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TRY_HIP(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->hintEvent, hipEventDisableTiming));
+    TRY_HIP(hipEventCreate(&c->tuneStart));
+    TRY_HIP(hipEventCreate(&c->tuneEnd));
     TRY_HIP(hipHostMalloc((void**)&c->liveHintHost, sizeof(uint32_t) * (PT_MAX_DEPTH + 2), hipHostMallocDefault));
     { const char* e = getenv("PT_SPARSE"); if (e) c->sparseMode = atoi(e); }
     for (int g = 0; g < kMaxStreamGroups; ++g) {
@@ -744,7 +760,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     }
     { const char* e = getenv("PT_SHADOW_OVERLAP"); if (e) c->shadowOverlap = atoi(e) != 0; }
     { const char* e = getenv("PT_ROWS_PER_GROUP"); if (e && atoi(e) > 0) c->rowsPerGroup = atoi(e); }
-    { const char* e = getenv("PT_STREAMS"); int v = e ? atoi(e) : kDefaultStreamGroups; c->streamGroups = std::max(1, std::min(v, kMaxStreamGroups)); }
+    { const char* e = getenv("PT_STREAMS"); int v = e ? atoi(e) : kDefaultStreamGroups; c->streamGroups = std::max(1, std::min(v, kMaxStreamGroups)); c->streamsFixed = e != nullptr; }
 
     /* ---- meshes: concatenated in geom order (src/pathtrace.cu:483-505), one BVH per mesh (:269-334) */
     std::vector<DGeom> geoms(d->geomCount);
@@ -908,7 +924,21 @@ static int traceBatch(PtContext* c, Batch bt)
      * several streams: while one group's traversal kernel drains its last long rays, the kernels of the
      * other groups fill the machine.  With stage timing on everything stays on one stream so that the
      * event-bracketed durations are those of kernels running alone. */
-    const int groups = (c->timing || !meshes) ? 1 : std::max(1, std::min(c->streamGroups, bt.count / c->rowsPerGroup));     /* no traversal, no tails to hide */
+    int groups = 1;                     /* stage timing, or no traversal and so no tails to hide: one stream */
+    bool tuning = false;
+    if (!c->timing && meshes) {
+        if (c->streamsFixed) groups = std::max(1, std::min(c->streamGroups, bt.count / c->rowsPerGroup));
+        else if (bt.count >= kTuneMinRows && count) { if (bt.count == c->tuneRows && c->tuneStage > kTuneShapes) groups = c->tuneChoice; }    /* counted kernels are no measure */
+        else if (bt.count >= kTuneMinRows) {
+            /* stages: 0 = a first group on one stream, unmeasured (first launches, no live-count hint yet);
+             * 1..kTuneShapes = measure that many streams; then the choice stands until the group size changes */
+            if (bt.count != c->tuneRows) { c->tuneRows = bt.count; c->tuneStage = 0; }
+            if (c->tuneStage == 0) groups = 1;
+            else if (c->tuneStage <= kTuneShapes) { groups = c->tuneStage; tuning = true; }
+            else groups = c->tuneChoice;
+        }
+    }
+    if (tuning) HIP_TRY(hipEventRecord(c->tuneStart, s));
     if (groups > 1) HIP_TRY(hipEventRecord(c->forkEvent, s));
     for (int g = 0; g < groups; ++g) {
         const int r0 = (int)((long long)bt.count * g / groups), r1 = (int)((long long)bt.count * (g + 1) / groups);
@@ -958,12 +988,28 @@ static int traceBatch(PtContext* c, Batch bt)
         }
     }
     ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc, shadowCount, closestCount, kMaxBatch);
+    if (tuning) {
+        HIP_TRY(hipEventRecord(c->tuneEnd, s));
+        HIP_TRY(hipEventSynchronize(c->tuneEnd));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->tuneStart, c->tuneEnd));
+        c->tuneMs[groups] = ms;
+        if (groups == kTuneShapes) {
+            c->tuneChoice = 1;
+            for (int g = 2; g <= kTuneShapes; ++g) if (c->tuneMs[g] < c->tuneMs[c->tuneChoice]) c->tuneChoice = g;
+            if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] launch shape for groups of %d: %d stream(s) (%.2f / %.2f / %.2f ms)\n", bt.count, c->tuneChoice, c->tuneMs[1], c->tuneMs[2], c->tuneMs[3]);
+        }
+    }
+    const bool tunePhase = !c->timing && meshes && !c->streamsFixed && !count && bt.count >= kTuneMinRows && c->tuneStage <= kTuneShapes;
+    if (tunePhase) c->tuneStage++;
     if (!c->hintPending) {
         HIP_TRY(hipMemcpyAsync(c->liveHintHost, (const char*)c->dc + offsetof(DevCounters, liveMax), sizeof(c->liveHint), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(c->hintEvent, s));
         c->hintPending = true;
     }
     HIP_TRY(hipGetLastError());
+    /* the unmeasured first group ends with a wait as well, so that the measured ones start with the live-count hint in place */
+    if (tunePhase && !tuning) HIP_TRY(hipStreamSynchronize(s));
     c->iterations += (uint64_t)bt.count;
     return PT_OK;
 }

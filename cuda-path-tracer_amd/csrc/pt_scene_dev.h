@@ -259,6 +259,7 @@ struct MeshTrav {
     int nodeStart, triStart;    /* of the mesh being walked, kept in registers: a per-step reload from the geom
                                    record would put one more dependent memory access in front of every node fetch */
     bool fast;                  /* origin and reciprocal direction are finite: no NaN can arise in a slab test */
+    uint32_t selX, selY, selZ;  /* fast rays: byte offset (0 or 48) of the plane array a slab is entered through, per axis */
 };
 
 PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
@@ -277,6 +278,10 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     const float INF = __builtin_inff();
     tv.fast = __builtin_fabsf(tv.invDir.x) < INF && __builtin_fabsf(tv.invDir.y) < INF && __builtin_fabsf(tv.invDir.z) < INF &&
               __builtin_fabsf(tv.lo.x) < INF && __builtin_fabsf(tv.lo.y) < INF && __builtin_fabsf(tv.lo.z) < INF;
+    /* a node stores its four child boxes as six plane arrays: min x, y, z at bytes 0, 16, 32 and max x, y, z at 48, 64, 80 */
+    tv.selX = tv.invDir.x < 0.0f ? 48u : 0u;
+    tv.selY = tv.invDir.y < 0.0f ? 48u : 0u;
+    tv.selZ = tv.invDir.z < 0.0f ? 48u : 0u;
 }
 
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
@@ -287,48 +292,67 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
     const float INF = __builtin_inff();
     const int ref = tv.ref;
     if (ref >= 0) {
-        const float4* q = S.nodes + 8 * ((size_t)tv.nodeStart + (size_t)ref);
-        float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-        float4 rf = q[6];
-        if (COUNT) {
-            cnt.nodes++;
-            cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
-                         (__float_as_int(rf.z) != kEmptyRef) + (__float_as_int(rf.w) != kEmptyRef);
-        }
         float tk[4];
         int rk[4];
         const F3 lo = tv.lo, invDir = tv.invDir;
         const float closestT = tv.closestT;
-#define PT_CHILD(k, C)                                                                              \
-        {                                                                                            \
-            float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;                   \
-            float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;                   \
-            float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;                   \
-            float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));        \
-            float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));        \
-            int cr = __float_as_int(rf.C);                                                           \
-            bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);     \
-            tk[k] = in ? tMin : INF;                                                                 \
-            rk[k] = cr;                                                                              \
-        }
-        /* Without NaNs the hardware min/max give the same values as the compare-and-select forms the
-         * reference's vector library uses (they can differ in the sign of a zero only, which no comparison
-         * below sees), at half the instructions.  A NaN needs 0 * inf, i.e. a non-finite reciprocal. */
+        if (tv.fast) {
+            /* With a finite origin and reciprocal direction no NaN can arise, and for a box with min <= max the
+             * smaller of (min - o) * inv and (max - o) * inv is the one whose plane the ray's direction sign names
+             * (subtraction and the multiplication by inv are monotone).  The entry planes are therefore picked by
+             * address — three offsets per ray — and the interval is max3 of the entry distances, min3 of the exit
+             * distances: the values the compare-and-select forms of the reference's vector library give (up to the
+             * sign of a zero, which no comparison below sees), at two thirds of the instructions.
+             * Empty slots fail: their boxes sit at +inf. */
+            const char* base = (const char*)S.nodes;
+            const uint32_t off = ((uint32_t)tv.nodeStart + (uint32_t)ref) * 128u;
+            const uint32_t exitOff = off + 48u;
+            const float4 nX = *(const float4*)(base + (off + tv.selX));
+            const float4 nY = *(const float4*)(base + (off + tv.selY) + 16);
+            const float4 nZ = *(const float4*)(base + (off + tv.selZ) + 32);
+            const float4 fX = *(const float4*)(base + (exitOff - tv.selX));
+            const float4 fY = *(const float4*)(base + (exitOff - tv.selY) + 16);
+            const float4 fZ = *(const float4*)(base + (exitOff - tv.selZ) + 32);
+            const float4 rf = *(const float4*)(base + off + 96);
+            if (COUNT) {
+                cnt.nodes++;
+                cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
+                             (__float_as_int(rf.z) != kEmptyRef) + (__float_as_int(rf.w) != kEmptyRef);
+            }
 #define PT_CHILD_FAST(k, C)                                                                         \
-        {                                                                                            \
-            float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;                   \
-            float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;                   \
-            float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;                   \
-            float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)), __builtin_fminf(az0, az1)); \
-            float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fmaxf(az0, az1)); \
-            bool in = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);   /* empty slots fail: boxes at +inf */ \
-            tk[k] = in ? tMin : INF;                                                                 \
-            rk[k] = __float_as_int(rf.C);                                                            \
-        }
-        if (tv.fast) { PT_CHILD_FAST(0, x) PT_CHILD_FAST(1, y) PT_CHILD_FAST(2, z) PT_CHILD_FAST(3, w) }
-        else { PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w) }
-#undef PT_CHILD
+            {                                                                                        \
+                float tMin = __builtin_fmaxf(__builtin_fmaxf((nX.C - lo.x) * invDir.x, (nY.C - lo.y) * invDir.y), (nZ.C - lo.z) * invDir.z); \
+                float tMax = __builtin_fminf(__builtin_fminf((fX.C - lo.x) * invDir.x, (fY.C - lo.y) * invDir.y), (fZ.C - lo.z) * invDir.z); \
+                bool in = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);                      \
+                tk[k] = in ? tMin : INF;                                                             \
+                rk[k] = __float_as_int(rf.C);                                                        \
+            }
+            PT_CHILD_FAST(0, x) PT_CHILD_FAST(1, y) PT_CHILD_FAST(2, z) PT_CHILD_FAST(3, w)
 #undef PT_CHILD_FAST
+        } else {
+            const float4* q = S.nodes + 8 * ((size_t)tv.nodeStart + (size_t)ref);
+            float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+            float4 rf = q[6];
+            if (COUNT) {
+                cnt.nodes++;
+                cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
+                             (__float_as_int(rf.z) != kEmptyRef) + (__float_as_int(rf.w) != kEmptyRef);
+            }
+#define PT_CHILD(k, C)                                                                              \
+            {                                                                                        \
+                float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;               \
+                float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;               \
+                float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;               \
+                float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));    \
+                float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));    \
+                int cr = __float_as_int(rf.C);                                                       \
+                bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT); \
+                tk[k] = in ? tMin : INF;                                                             \
+                rk[k] = cr;                                                                          \
+            }
+            PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
+#undef PT_CHILD
+        }
         /* nearest first: 5-exchange network on (distance, ref) */
 #define PT_CSWAP(i, j) { bool sw = tk[j] < tk[i]; float tt_ = sw ? tk[j] : tk[i]; float tu_ = sw ? tk[i] : tk[j]; \
                          int ra_ = sw ? rk[j] : rk[i]; int rb_ = sw ? rk[i] : rk[j]; tk[i] = tt_; tk[j] = tu_; rk[i] = ra_; rk[j] = rb_; }

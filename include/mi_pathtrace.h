@@ -234,8 +234,10 @@ int pt_trace(PtContext* ctx, int iter);
 /* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end.  Up to
  * PT_OPT_BATCH iterations form a launch group that runs through the same kernel
  * launches (each iteration with its own path state and queues, so results equal one
- * pt_trace call per iteration, bit for bit); a group is spread over three streams
- * internally (environment PT_STREAMS, 1..8) and joined on the context's stream. */
+ * pt_trace call per iteration, bit for bit); a group runs on one to three streams
+ * internally and is joined on the context's stream: the first four groups of a size
+ * (12 iterations or more) try the shapes, each of those calls ends with a wait, and the
+ * fastest is kept (environment PT_STREAMS, 1..8, fixes the count instead). */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE
