@@ -710,6 +710,20 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(float* image, float* part
     image[i] = acc;
 }
 
+/* the same, four floats per lane (16-byte accesses); n4 = n3 / 4, for 16-byte aligned buffers with n3 % 4 == 0 */
+__global__ void __launch_bounds__(kBlock) k_accumulate4(float4* image, float4* partial, size_t n4, int batch)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = image[i];
+    for (int k = 0; k < batch; ++k) {
+        float4 v = partial[(size_t)k * n4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        partial[(size_t)k * n4 + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    image[i] = acc;
+}
+
 /* sendImageToPBO (src/pathtrace.cu:145-166): (int)(sum / iter * 255.0) with a double 255.0 */
 __global__ void __launch_bounds__(kBlock) k_display(const float* image, int n, int iter, uint8_t* rgba)
 {
@@ -864,7 +878,10 @@ void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, floa
     hipLaunchKernelGGL(k_final_gather, slotGrid(q, bt), dim3(kBlock), 0, s, st, q, depth);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, bt.count, (DevCounters*)dc, shadowCounts, closestCounts, rowStride);
     const size_t n3 = 3 * st.numPixels;
-    hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, bt.count);
+    if (n3 % 4 == 0 && (((uintptr_t)image | (uintptr_t)st.image) & 15u) == 0)
+        hipLaunchKernelGGL(k_accumulate4, dim3(gridFor((long long)(n3 / 4))), dim3(kBlock), 0, s, (float4*)image, (float4*)st.image, n3 / 4, bt.count);
+    else
+        hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, bt.count);
 }
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba)
 {
