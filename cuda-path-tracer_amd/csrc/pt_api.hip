@@ -995,8 +995,11 @@ static int traceBatch(PtContext* c, Batch bt)
         HIP_TRY(hipEventElapsedTime(&ms, c->tuneStart, c->tuneEnd));
         c->tuneMs[groups] = ms;
         if (groups == kTuneShapes) {
+            /* more streams only when they pay: the fewest streams within 2 % of the fastest shape */
+            float best = c->tuneMs[1];
+            for (int g = 2; g <= kTuneShapes; ++g) best = std::min(best, c->tuneMs[g]);
             c->tuneChoice = 1;
-            for (int g = 2; g <= kTuneShapes; ++g) if (c->tuneMs[g] < c->tuneMs[c->tuneChoice]) c->tuneChoice = g;
+            while (c->tuneChoice < kTuneShapes && c->tuneMs[c->tuneChoice] > 1.02f * best) c->tuneChoice++;
             if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] launch shape for groups of %d: %d stream(s) (%.2f / %.2f / %.2f ms)\n", bt.count, c->tuneChoice, c->tuneMs[1], c->tuneMs[2], c->tuneMs[3]);
         }
     }

@@ -14,7 +14,8 @@ import sys
 from collections import defaultdict
 
 NAMES = {"k_trace<0, false>": "k_trace(closest)", "k_trace<1, false>": "k_trace(shadow)",
-         "k_shade<false>": "k_shade", "k_prims<false>": "k_prims", "k_cull": "k_cull"}
+         "k_shade<false, false>": "k_shade", "k_prims<false, false>": "k_prims",
+         "k_shade<false, true>": "k_shade(sparse form)", "k_prims<false, true>": "k_prims(sparse form)", "k_cull": "k_cull"}
 
 
 def per_dispatch(root, counter):

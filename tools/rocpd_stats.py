@@ -21,15 +21,21 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--csv")
     ap.add_argument("--grid", action="store_true")
+    ap.add_argument("--match", help="only kernels whose name contains this")
+    ap.add_argument("--last", type=int, help="only the last N calls of every row (e.g. the final pass of a run)")
     a = ap.parse_args()
     db = sqlite3.connect(a.db)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
     sel = "name, (end - start)" + (", 'grid ' || %s || 'x' || grid_y" % gcol if (a.grid and gcol) else "")
     rows = {}
-    for r in db.execute("select %s from kernels" % sel):
+    for r in db.execute("select %s from kernels order by start" % sel):
+        if a.match and a.match not in r[0]:
+            continue
         key = (short(r[0]),) + tuple(r[2:])
         rows.setdefault(key, []).append(r[1])
+    if a.last:
+        rows = {k: v[-a.last:] for k, v in rows.items()}
     total = sum(sum(v) for v in rows.values())
     out = []
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
