@@ -816,8 +816,10 @@ static inline dim3 slotGrid(const Queues& q, const Batch& bt)
 static inline int persistentGridX(int batch)
 {
     static const int total = [] { const char* e = getenv("PT_PERSIST_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    /* 256 CUs x 4 workgroups of 4 waves = 16 waves per CU in flight; split over the batch rows */
-    int x = (total + batch - 1) / batch;
+    /* 256 CUs x 4 workgroups of 4 waves = 16 waves per CU in flight; split over the batch rows.  Rounded DOWN: a
+     * workgroup only serves its own row, so workgroups beyond what the machine holds at once would start when the
+     * others are done and walk the last rows alone (1071 workgroups for 63 rows cost 30 % on a large scene). */
+    int x = total / batch;
     return x < 1 ? 1 : x;
 }
 /* intersect stage = cull (work list of the traversal) + trace (BVH meshes) + prims (everything else, hit record, sort bucket) */
