@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
      * part of the BVH. */
     uint32_t* ctr = fetchCtr + blockIdx.y * kCtrStride;
     int seg = (int)((blockIdx.y * gridDim.x + blockIdx.x) % kSegments);
-    int segsLeft = kSegments;
+    int segsLeft = kSegments;       /* 0 once every piece has been seen dry */
+    bool needScan = false;
     int* stack = s_stack + tid;
     int ovRef[kOverflowStack];
     float ovT[kOverflowStack];
@@ -236,6 +237,8 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
     unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
 
+    /* every wave leaves this loop: a lane's walk ends when its stack is empty, a wave stops fetching once all
+     * eight pieces have been seen dry, and then breaks out as soon as no lane is walking */
     while (true) {
         const unsigned long long idle = __ballot(!trav && !exhausted);
         if (__ballot(trav) == 0 || __builtin_popcountll(idle) >= kRefillThreshold) {
@@ -285,6 +288,24 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 const unsigned long long fm = __ballot(fetch);
                 if (fm == 0) break;
                 if (segsLeft == 0) { if (fetch) exhausted = true; break; }
+                if (needScan) {
+                    needScan = false;
+                    /* the piece this wave was on is used up: read all eight counters (one cache line) and go to the next
+                     * piece that still has entries, instead of finding every dry piece with an atomic of its own —
+                     * at the end of a launch thousands of waves do that at once, and their atomics on one line took
+                     * longer than the last rays.  The counters only grow, so a stale value costs at worst the atomic
+                     * it was meant to save. */
+                    int foundDist = kSegments;
+#pragma unroll
+                    for (int k = 0; k < kSegments; ++k) {
+                        const uint32_t len = (uint32_t)(((unsigned long long)n * (unsigned)(k + 1)) / kSegments) - (uint32_t)(((unsigned long long)n * (unsigned)k) / kSegments);
+                        const uint32_t cur = __hip_atomic_load(ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int dist = (k - seg) & (kSegments - 1);
+                        if (cur < len && dist < foundDist) foundDist = dist;
+                    }
+                    if (foundDist == kSegments) { segsLeft = 0; if (fetch) exhausted = true; break; }
+                    seg = (seg + foundDist) & (kSegments - 1);
+                }
                 const uint32_t segBegin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / kSegments);
                 const uint32_t segLen = (uint32_t)(((unsigned long long)n * (unsigned)(seg + 1)) / kSegments) - segBegin;
                 const uint32_t want = (uint32_t)__builtin_popcountll(fm);
@@ -292,7 +313,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 uint32_t base = 0;
                 if (lane == leader) base = atomicAdd(ctr + seg, want);
                 base = (uint32_t)__shfl((int)base, leader);
-                if (base + want >= segLen) { seg = (seg + 1) % kSegments; --segsLeft; }     /* this piece is used up */
+                if (base + want >= segLen) { seg = (seg + 1) % kSegments; needScan = true; }     /* this piece is used up */
                 if (fetch) {
                     const uint32_t sloc = base + (uint32_t)__builtin_popcountll(fm & lt);
                     if (sloc < segLen) {
