@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     st = st.at(blockIdx.y);
     q = q.at(blockIdx.y);
     const uint32_t n = workCount[blockIdx.y * kCtrStride];
-    if (n == 0) return;
+    /* a short queue does not need every workgroup of the row: those beyond one ray per lane leave at once, without
+     * touching the counters (late bounces hold a few thousand rays per row) */
+    if ((uint32_t)blockIdx.x * kBlock >= n) return;
     /* The work queue is cut into kSegments contiguous pieces with a fetch counter each (dwords 0..7 of the row's
      * counter line).  Workgroups are dealt round-robin over the 8 XCDs, so (linear workgroup id) % 8 names the
      * groups that share an L2: each starts on "its" piece and moves on to the others when that runs dry.  Queues
