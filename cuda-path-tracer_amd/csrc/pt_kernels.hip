@@ -690,32 +690,41 @@ __global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q,
 }
 
 /* per-batch bookkeeping: path-bounce total over the batch, live curve of its last iteration */
-__global__ void k_finish(Queues q0, int depth, int batch, DevCounters* dc, const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride)
+__global__ void __launch_bounds__(64) k_finish(Queues q0, int depth, int batch, DevCounters* dc, const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    /* one wave: lane t takes rows t, t + 64, ...; sums and maxima are folded across the lanes */
+    const int lane = threadIdx.x;
     unsigned long long s = 0, wc = 0, ws = 0;
-    for (int b = 0; b < depth; ++b)
-        for (int k = 0; k < batch; ++k) {
+    uint32_t mx[PT_MAX_DEPTH + 2];
+    for (int b = 0; b <= depth; ++b) mx[b] = 0;
+    for (int k = lane; k < batch; k += 64) {
+        for (int b = 0; b < depth; ++b) {
             wc += closestCounts[((size_t)b * rowStride + k) * kCtrStride];
             ws += shadowCounts[((size_t)b * rowStride + k) * kCtrStride];
         }
-    dc->workItems[0] += wc;
-    dc->workItems[1] += ws;
-    for (int k = 0; k < batch; ++k) {
         Queues q = q0.at(k);
-        for (int b = 0; b < depth; ++b) {
-            uint32_t v = q.live[b];
-            s += v;
-            if (v == 0) break;
-        }
+        bool open = true;
         for (int b = 0; b <= depth; ++b) {
-            uint32_t v = q.live[b];
-            if (k == 0 || v > dc->liveMax[b]) dc->liveMax[b] = v;
+            const uint32_t v = q.live[b];
+            if (open && b < depth) { s += v; if (v == 0) open = false; }
+            if (v > mx[b]) mx[b] = v;
+            if (k == batch - 1) dc->lastLive[b] = v;
         }
-        if (k == batch - 1)
-            for (int b = 0; b <= depth; ++b) dc->lastLive[b] = q.live[b];
     }
-    dc->pathBounces += s;
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off); wc += __shfl_down(wc, off); ws += __shfl_down(ws, off);
+    }
+    for (int b = 0; b <= depth; ++b) {
+        uint32_t m = mx[b];
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o = (uint32_t)__shfl_down((int)m, off); if (o > m) m = o; }
+        if (lane == 0) dc->liveMax[b] = m;
+    }
+    if (lane == 0) {
+        dc->workItems[0] += wc;
+        dc->workItems[1] += ws;
+        dc->pathBounces += s;
+    }
 }
 
 /* image += contribution of iteration 0, then 1, ... : the order one-iteration-at-a-time accumulation
