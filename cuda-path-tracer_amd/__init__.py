@@ -145,6 +145,7 @@ def _load():
         "pt_scene_import_gltf": (ip, [vp, C.c_char_p, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
         "pt_scene_log": (C.c_char_p, [vp]),
         "pt_decode_png": (ip, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "pt_decode_jpeg": (ip, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "pt_image_to_rgb8": (ip, [vp, ip, ip, fp, vp]),
         "pt_image_average": (ip, [vp, ip, ip, fp, ip, vp]),
         "pt_write_png": (ip, [C.c_char_p, vp, ip, ip, ip]),
@@ -228,6 +229,16 @@ def decode_png(data):
     _check(lib.pt_decode_png(buf.ctypes.data, len(buf), None, 0, C.byref(w), C.byref(h)), "pt_decode_png")
     out = np.empty((h.value, w.value, 4), np.uint8)
     _check(lib.pt_decode_png(buf.ctypes.data, len(buf), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)), "pt_decode_png")
+    return out
+
+
+def decode_jpeg(data):
+    """Sequential JPEG bytes -> (H, W, 4) uint8 (the texture path of the glTF import)."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_int(), C.c_int()
+    _check(lib.pt_decode_jpeg(buf.ctypes.data, len(buf), None, 0, C.byref(w), C.byref(h)), "pt_decode_jpeg")
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    _check(lib.pt_decode_jpeg(buf.ctypes.data, len(buf), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)), "pt_decode_jpeg")
     return out
 
 

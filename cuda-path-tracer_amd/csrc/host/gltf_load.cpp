@@ -1,6 +1,6 @@
 /*
  * gltf_load.cpp — glTF 2.0 import: container (.glb chunks, .gltf with external or base64 buffers),
- * node hierarchy, triangle primitives, metallic-roughness materials, PNG textures.  No GPU calls.
+ * node hierarchy, triangle primitives, metallic-roughness materials, PNG / JPEG textures.  No GPU calls.
  *
  * Behaviour follows Scene::loadGLTFModel / loadGLTFMaterial / loadGLTFTexture (src/scene.cpp:44-568),
  * including the parts that decide the numbers the tracer sees:
@@ -24,9 +24,11 @@
  * Deliberate differences: accessor byteStride is honoured (the reference assumes tightly packed data);
  * the scalars the reference leaves uninitialised in an imported Material (specular exponent, index of
  * refraction, subsurface radius / scale / anisotropy / enabled, src/scene.cpp:96) are 0, 1.5, 0, 0, 0, 0;
- * images that are not 8-bit PNG are skipped with a warning (texture index -1) instead of failing the load.
+ * images that are neither 8-bit PNG nor sequential 8-bit JPEG (16-bit PNG, progressive JPEG, other formats) are
+ * skipped with a warning (texture index -1) instead of failing the load.
  */
 #include "gltf_load.h"
+#include "jpeg_decode.h"
 #include "json_min.h"
 #include "png_decode.h"
 
@@ -268,7 +270,8 @@ bool loadTextureImage(const Doc& d, const Value& tex, Image& img, std::string& w
         if (!loadUri(uri->str, d.baseDir, holder)) { why = "cannot load image " + uri->str.substr(0, 64); return false; }
         p = holder.data(); n = holder.size();
     } else { why = "image without data"; return false; }
-    if (!ptpng::decode(p, n, img.pixels, img.width, img.height, why)) return false;
+    const bool jpeg = n >= 2 && p[0] == 0xff && p[1] == 0xd8;
+    if (jpeg ? !ptjpg::decode(p, n, img.pixels, img.width, img.height, why) : !ptpng::decode(p, n, img.pixels, img.width, img.height, why)) return false;
     img.components = 4;
     return true;
 }

@@ -21,6 +21,7 @@
 #include "../../../include/mi_pathtrace.h"
 #include "gltf_load.h"
 #include "json_min.h"
+#include "jpeg_decode.h"
 #include "png_decode.h"
 #include "xform.h"
 
@@ -490,6 +491,19 @@ int pt_decode_png(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity
     if (!ptpng::decode(bytes, n, px, *width, *height, why)) { pt_set_error("pt_decode_png: %s", why.c_str()); return PT_EIO; }
     if (rgba) {
         if (capacity < px.size()) { pt_set_error("pt_decode_png: output buffer too small"); return PT_EINVAL; }
+        memcpy(rgba, px.data(), px.size());
+    }
+    return PT_OK;
+}
+
+int pt_decode_jpeg(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height)
+{
+    if (!bytes || !width || !height) { pt_set_error("pt_decode_jpeg: null argument"); return PT_EINVAL; }
+    std::vector<uint8_t> px;
+    std::string why;
+    if (!ptjpg::decode(bytes, n, px, *width, *height, why)) { pt_set_error("pt_decode_jpeg: %s", why.c_str()); return PT_EIO; }
+    if (rgba) {
+        if (capacity < px.size()) { pt_set_error("pt_decode_jpeg: output buffer too small"); return PT_EINVAL; }
         memcpy(rgba, px.data(), px.size());
     }
     return PT_OK;

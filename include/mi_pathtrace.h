@@ -322,8 +322,8 @@ int pt_scene_set_depth(PtScene* s, int depth);
 int pt_scene_add_mesh(PtScene* s, const PtTriangle* tris, int n,
                       const float translation[3], const float rotation[3], const float scale[3]);
 /* Scene::loadGLTFModel + loadGLTFMaterial + loadGLTFTexture (src/scene.cpp:44-568): import a .glb / .gltf
- * file as one mesh object under the TRS triple — its textures (8-bit PNG, expanded to RGBA8 as tinygltf /
- * stb_image do for the reference) and materials are appended to the scene's tables, the triangles of every
+ * file as one mesh object under the TRS triple — its textures (8-bit PNG or sequential JPEG, expanded to RGBA8 as
+ * tinygltf / stb_image do for the reference) and materials are appended to the scene's tables, the triangles of every
  * scene node are baked into world space (node "matrix" read transposed, as src/scene.cpp:286-292 does).
  * pt_scene_load calls this for every object of TYPE "gltf" (src/scene.cpp:863-884); a file that cannot be
  * read leaves that object empty there, as in the reference.  Returns the geom index, or PT_EIO. */
@@ -336,6 +336,10 @@ const char* pt_scene_log(const PtScene* s);
  * inside tinygltf, external/include/tiny_gltf.h): writes width*height*4 bytes when rgba is not NULL and
  * capacity suffices; call with rgba == NULL to learn the size. */
 int pt_decode_png(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height);
+/* The same for sequential 8-bit JPEG streams; follows stb_image's integer inverse DCT, chroma upsampling and
+ * YCbCr -> RGB arithmetic (external/include/stb_image.h:2426-2524, :3465-3527, :3659-3683).  Progressive
+ * files are refused. */
+int pt_decode_jpeg(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height);
 int pt_scene_add_material(PtScene* s, const PtMaterial* m);
 int pt_scene_add_texture(PtScene* s, const uint8_t* data, int w, int h, int comps);
 int pt_scene_set_envmap(PtScene* s, const float* rgb, int w, int h, float intensity);

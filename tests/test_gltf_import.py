@@ -353,3 +353,83 @@ def test_reference_duck_scene_known_answers(pt, orc):
         nodes, idx, st = build()
         assert (st["nodes"], st["leaves"], st["max_depth"]) == (k["nodes"], k["leaves"], k["max_depth"])
         assert sorted(idx.tolist()) == list(range(len(tris)))
+
+
+# ------------------------------------------------------------------ JPEG
+
+def _smooth_image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 7.0 + seed) * np.cos(y / 9.0), 128 + 90 * np.cos(x / 5.0) * np.sin(y / 11.0 + 1), 128 + 110 * np.sin((x + y) / 13.0)], -1)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("sampling", [(1, 1), (2, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("size", [(16, 16), (37, 53), (8, 9), (1, 1), (64, 33)])
+def test_jpeg_decoder_against_independent_float_decode(pt, sampling, size):
+    """Baseline JPEG written by tests/jpeg_util.py (every chroma sampling the upsampler treats specially, sizes
+    off the MCU grid, with and without restart intervals): the library's integer decode stays within 4 levels of
+    the float decode of the very coefficients the file stores."""
+    import jpeg_util as J
+    img = _smooth_image(size[0], size[1], sampling[0] * 3 + sampling[1])
+    for restart in (0, 3):
+        data, info = J.encode(img, sampling=sampling, restart=restart)
+        got = pt.decode_jpeg(data).astype(np.float64)
+        exp = J.expected(info)
+        assert got.shape == exp.shape
+        assert np.abs(got - exp).max() <= 4.0, (sampling, size, restart, float(np.abs(got - exp).max()))
+        assert (got[..., 3] == 255).all()
+        # and the file really is a lossy version of the picture, not something else
+        assert np.abs(got[..., :3] - img).mean() < 14
+
+
+def test_jpeg_grey_rgb_and_marker_rules(pt):
+    import jpeg_util as J
+    grey = _smooth_image(21, 30, 5)[..., 0]
+    data, info = J.encode(grey)
+    got = pt.decode_jpeg(data)
+    assert np.abs(got.astype(np.float64) - J.expected(info)).max() <= 2 and (got[..., 0] == got[..., 1]).all() and (got[..., 1] == got[..., 2]).all()
+    img = _smooth_image(24, 24, 6)
+    # component ids 'R','G','B': planes are taken as they are
+    data, info = J.encode(img, rgb_ids=True)
+    assert np.abs(pt.decode_jpeg(data).astype(np.float64) - J.expected(info)).max() <= 2
+    # Adobe marker with transform 0 and no JFIF marker: RGB as well; with a JFIF marker the file counts as YCbCr
+    data, info = J.encode(img, jfif=False, adobe=0)
+    raw = dict(info, rgb=True)
+    assert np.abs(pt.decode_jpeg(data).astype(np.float64) - J.expected(raw)).max() <= 2
+    data, info = J.encode(img, jfif=True, adobe=0)
+    assert np.abs(pt.decode_jpeg(data).astype(np.float64) - J.expected(info)).max() <= 3
+
+
+def test_jpeg_rejects_what_it_cannot_read(pt):
+    import jpeg_util as J
+    data, _ = J.encode(_smooth_image(16, 16, 1))
+    with pytest.raises(pt.PtError, match="progressive"):
+        pt.decode_jpeg(data.replace(b"\xff\xc0", b"\xff\xc2", 1))
+    for bad in (b"", b"\xff\xd8", data[:40], data[:len(data) // 2].replace(b"\xff\xda", b"\xff\xdb", 1)):
+        with pytest.raises(pt.PtError):
+            pt.decode_jpeg(bad)
+    # a truncated scan still gives an image of the right size (missing blocks decode from zero bits)
+    cut = pt.decode_jpeg(data[:len(data) - 40] + b"\xff\xd9")
+    assert cut.shape == (16, 16, 4)
+
+
+def test_glb_with_jpeg_texture(pt, scenes, tmp_path):
+    import jpeg_util as J
+    img = _smooth_image(32, 32, 9)
+    data, info = J.encode(img, sampling=(2, 2))
+    b = G.GlbBuilder()
+    bv = b._view(data)
+    b.doc["images"].append(dict(bufferView=bv, mimeType="image/jpeg"))
+    b.doc["textures"].append(dict(source=0))
+    b.material(pbrMetallicRoughness=dict(baseColorTexture=dict(index=0)))
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], f32)
+    b.node(root=True, mesh=b.mesh([dict(attributes=dict(POSITION=b.accessor(pos, "VEC3", 5126)), material=0)]))
+    b.write_glb(tmp_path / "j.glb")
+    sc = _base_scene(pt, scenes, tmp_path)
+    sc.import_gltf(tmp_path / "j.glb")
+    tex = sc.textures()
+    assert sc.log == "" and len(tex) == 1 and tex[0].shape == (32, 32, 4)
+    assert np.array_equal(tex[0], pt.decode_jpeg(data))
+    assert sc.materials()[-1].baseColorTextureIdx == 0

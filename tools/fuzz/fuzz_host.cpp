@@ -16,7 +16,8 @@ int main(int argc, char** argv)
     int rounds = atoi(argv[4]);
     std::mt19937 rng(argc > 6 ? atoi(argv[6]) : 12345);
     const float t[3] = {0, 0, 0}, s[3] = {1, 1, 1};
-    int okGlb = 0, okPng = 0, okScene = 0;
+    int okGlb = 0, okPng = 0, okScene = 0, okJpg = 0;
+    std::vector<uint8_t> jpg = argc > 7 ? slurp(argv[7]) : std::vector<uint8_t>();
     std::string dir = argv[5];
     for (int r = 0; r < rounds; ++r) {
         auto mutate = [&](std::vector<uint8_t> d) {
@@ -38,6 +39,13 @@ int main(int argc, char** argv)
             std::vector<uint8_t> out(1 << 22);
             if (pt_decode_png(d.data(), d.size(), out.data(), out.size(), &w, &h) == PT_OK) ++okPng;
         }
+        if (!jpg.empty()) {   // JPEG
+            std::vector<uint8_t> d = mutate(jpg);
+            int w, h;
+            std::vector<uint8_t> out(1 << 22);
+            if (pt_decode_jpeg(d.data(), d.size(), nullptr, 0, &w, &h) == PT_OK && (size_t)w * h * 4 <= out.size() &&
+                pt_decode_jpeg(d.data(), d.size(), out.data(), out.size(), &w, &h) == PT_OK) ++okJpg;
+        }
         {   // GLB (mutations mostly in the first 3000 bytes: header + JSON)
             std::vector<uint8_t> d = glb;
             if (rng() % 2) { size_t keep = d.size(); d.resize(3000 < keep ? 3000 : keep); d = mutate(d); d.insert(d.end(), glb.begin() + (3000 < keep ? 3000 : keep), glb.end()); }
@@ -58,6 +66,6 @@ int main(int argc, char** argv)
             if (pt_scene_load(p.c_str(), &sc) == PT_OK) { ++okScene; pt_scene_free(sc); }
         }
     }
-    printf("rounds %d: png ok %d, glb ok %d, scene ok %d\n", rounds, okPng, okGlb, okScene);
+    printf("rounds %d: png ok %d, jpeg ok %d, glb ok %d, scene ok %d\n", rounds, okPng, okJpg, okGlb, okScene);
     return 0;
 }

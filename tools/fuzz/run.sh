@@ -17,14 +17,16 @@ import conftest
 pt = conftest.load_package()
 scenes = importlib.import_module("cuda_path_tracer_amd.scenes")
 import glb_util as G
+import jpeg_util as J
 import test_gltf_import as T
 d = pathlib.Path(sys.argv[1])
 T._build_test_glb(d, "seed.glb")
 (d / "seed.png").write_bytes(G.write_png(np.random.default_rng(1).integers(0, 256, (24, 24, 4), dtype=np.uint8), 6, interlace=True))
+(d / "seed.jpg").write_bytes(J.encode(T._smooth_image(40, 56, 2), sampling=(2, 2), restart=2)[0])
 sd = scenes.scene_dict("cornell")
 sd["Objects"].append(dict(TYPE="gltf", FILE="seed.glb", TRANS=[0, 1, 0], ROTAT=[0, 0, 0], SCALE=[1, 1, 1]))
 (d / "seed.json").write_text(json.dumps(sd))
 base = dict(Materials={"a": dict(TYPE="Diffuse", RGB=[1, 1, 1])}, Camera=scenes._camera("g", 4, 1, res=(8, 8)), Objects=[])
 (d / "base.json").write_text(json.dumps(base))
 PY
-"$ROOT/build/fuzz/fuzz_host" "$W/seed.glb" "$W/seed.png" "$W/seed.json" "${1:-3000}" "$W" "${2:-12345}"
+"$ROOT/build/fuzz/fuzz_host" "$W/seed.glb" "$W/seed.png" "$W/seed.json" "${1:-3000}" "$W" "${2:-12345}" "$W/seed.jpg"
