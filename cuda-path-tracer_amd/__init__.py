@@ -124,6 +124,8 @@ def _load():
         "pt_clear": (ip, [vp]),
         "pt_sync": (ip, [vp]),
         "pt_set_option": (ip, [vp, ip, ip]),
+        "pt_capture_gbuffer": (ip, [vp, ip, vp, vp]),
+        "pt_denoise": (ip, [vp, fp, ip, fp, fp, fp, vp]),
         "pt_stats": (ip, [vp, C.POINTER(PtStats)]),
         "pt_reset_stats": (ip, [vp]),
         "pt_stream": (vp, [vp]),
@@ -426,6 +428,22 @@ class Tracer:
         s = PtStats()
         _check(lib.pt_stats(self._h, C.byref(s)), "pt_stats")
         return s
+
+    def capture_gbuffer(self, iteration):
+        """First-hit normals and base colours of the camera rays of one iteration: two (H, W, 3) float32 arrays."""
+        w, h = self.width, self.height
+        n = np.empty((h, w, 3), np.float32)
+        a = np.empty((h, w, 3), np.float32)
+        _check(lib.pt_capture_gbuffer(self._h, int(iteration), n.ctypes.data, a.ctypes.data), "pt_capture_gbuffer")
+        return n, a
+
+    def denoise(self, samples, levels=5, sigma_color=0.6, sigma_normal=0.3, sigma_albedo=0.3):
+        """A-trous filtered (sum / samples) guided by the captured buffers: (H, W, 3) float32."""
+        w, h = self.width, self.height
+        out = np.empty((h, w, 3), np.float32)
+        _check(lib.pt_denoise(self._h, float(samples), int(levels), float(sigma_color), float(sigma_normal), float(sigma_albedo),
+                              out.ctypes.data), "pt_denoise")
+        return out
 
     def reset_stats(self):
         _check(lib.pt_reset_stats(self._h), "pt_reset_stats")

@@ -3,11 +3,14 @@
  * pathtraceInit once, pathtrace(nullptr, 0, iteration) for iteration = 1..N exactly as runCuda does
  * (src/main.cpp:812-837), write the image.
  *
- *   pt_headless scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch]
+ *   pt_headless scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch] [--denoise]
  *
  * .png / .ppm hold the 8-bit image saveImage() + Image::savePNG produce (samples averaged, x mirrored,
  * clamped to [0,1]; src/main.cpp:351-375, src/image.cpp:23-43), .hdr the Radiance file of Image::saveHDR
  * (src/image.cpp:45-50), .pfm the unmirrored float average (bottom row first as the format demands).
+ * --denoise filters the result the way the reference's denoiser step does after the last iteration
+ * (src/pathtrace.cu:2885-2910: guide buffers from the first hits, filtered image copied to the host image),
+ * with the library's open a-trous filter in place of the closed OptiX one.
  * Without -o the image goes to <FILE of the camera block>.<iterations>samp.png, the reference's naming
  * without its start-time part.
  */
@@ -27,9 +30,9 @@ static bool endsWith(const std::string& s, const char* suf)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch] [--denoise]\n", argv[0]); return 2; }
     int iterations = -1, W = 0, H = 0, depth = 0;
-    bool batch = false;
+    bool batch = false, denoise = false;
     std::string out;
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "-n") && i + 1 < argc) iterations = atoi(argv[++i]);
@@ -37,6 +40,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "-d") && i + 1 < argc) depth = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
         else if (!strcmp(argv[i], "--batch")) batch = true;
+        else if (!strcmp(argv[i], "--denoise")) denoise = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     Scene* scene = nullptr;
@@ -64,6 +68,13 @@ int main(int argc, char** argv)
     const int w = d->camera.resolution[0], h = d->camera.resolution[1];
     const float* img = pt_scene_image(scene);
     const float samples = (float)(iterations > 0 ? iterations : 1);
+    if (denoise) {
+        std::vector<float> filtered(3 * (size_t)w * h);
+        if (pt_capture_gbuffer(pathtraceContext(), 1, nullptr, nullptr) != PT_OK ||
+            pt_denoise(pathtraceContext(), samples, 5, 2.0f, 0.35f, 0.25f, filtered.data()) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
+        float* host = pt_scene_image(scene);
+        for (size_t i = 0; i < filtered.size(); ++i) host[i] = filtered[i] * samples;      /* the host image holds sums */
+    }
     int rc = PT_OK;
     if (endsWith(out, ".png") || endsWith(out, ".ppm")) {
         /* what saveImage() + Image::savePNG produce: averaged, x mirrored, clamped, 8 bit */

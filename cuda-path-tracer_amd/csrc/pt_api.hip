@@ -34,6 +34,10 @@ void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
+void ptl_gbuffer(hipStream_t s, PathState st, const PtMaterial* materials, int n, float* normals, float* albedo);
+void ptl_average(hipStream_t s, const float* sum, float samples, size_t n3, float* out);
+void ptl_atrous(hipStream_t s, const float* in, const float* normals, const float* albedo, int W, int H, int step,
+                float invSigmaC2, float invSigmaN2, float invSigmaA2, float* out);
 void ptl_import_rays(hipStream_t s, PathState st, Queues q, const float* o, const float* d, int n);
 void ptl_export_hits(hipStream_t s, PathState st, int n, PtHit* out);
 void ptl_export_rays(hipStream_t s, PathState st, int n, float* o, float* d);
@@ -105,6 +109,9 @@ struct PtContext {
     bool ownImage = true;
     float* imageOwned = nullptr;
     float* imageSum = nullptr;          /* the running sum (owned or caller-bound) */
+    float *gNormals = nullptr, *gAlbedo = nullptr;      /* guide buffers of pt_capture_gbuffer (allocated on first use) */
+    float *dnA = nullptr, *dnB = nullptr;               /* ping-pong images of pt_denoise */
+    bool gbufferValid = false;
     /* options */
     int sortOn = 1, useBvh = 1, timing = 0, counters = 0;
     int batch = 0;                      /* iterations the allocated path state can hold */
@@ -1199,6 +1206,59 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
     }
     (void)hipFree(dO); if (dD) (void)hipFree(dD); if (dH) (void)hipFree(dH);
     return rc;
+}
+
+int pt_capture_gbuffer(PtContext* c, int iter, float* normals, float* albedo)
+{
+    if (!c) { pt_set_error("pt_capture_gbuffer: null context"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->numPixels;
+    if (!c->gNormals) { int rc = devAlloc(c, &c->gNormals, n * 3); if (rc != PT_OK) return rc; }
+    if (!c->gAlbedo) { int rc = devAlloc(c, &c->gAlbedo, n * 3); if (rc != PT_OK) return rc; }
+    /* camera rays of this iteration through the production intersect stage, on row 0 of the path state */
+    SceneView V = c->view;
+    V.useBvh = c->useBvh;
+    V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
+    uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch * kCtrStride;     /* a slot no bounce of a trace uses */
+    Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
+    HIP_TRY(hipMemsetAsync(ctr, 0, kCtrStride * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream));
+    ptl_camera(c->stream, V, c->cam, bt, c->traceDepth, c->state, c->queues, V.numBvhMeshes > 0 ? ctr + 3 * kWorkCtrSection : nullptr);
+    if (V.numBvhMeshes > 0) ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, ctr, ctr + 3 * kWorkCtrSection, nullptr);
+    ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr, false);
+    ptl_gbuffer(c->stream, c->state, V.materials, (int)n, c->gNormals, c->gAlbedo);
+    HIP_TRY(hipGetLastError());
+    if (normals) HIP_TRY(hipMemcpyAsync(normals, c->gNormals, n * 12, hipMemcpyDeviceToHost, c->stream));
+    if (albedo) HIP_TRY(hipMemcpyAsync(albedo, c->gAlbedo, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->gbufferValid = true;
+    return PT_OK;
+}
+
+int pt_denoise(PtContext* c, float samples, int levels, float sigma_color, float sigma_normal, float sigma_albedo, float* out_rgb)
+{
+    if (!c || !out_rgb || !(samples > 0.0f) || levels < 1 || levels > 8 || !(sigma_color > 0.0f)) { pt_set_error("pt_denoise: bad argument"); return PT_EINVAL; }
+    if ((sigma_normal > 0.0f || sigma_albedo > 0.0f) && !c->gbufferValid) { pt_set_error("pt_denoise: guide buffers wanted but pt_capture_gbuffer has not run"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n3 = (size_t)c->numPixels * 3;
+    if (!c->dnA) { int rc = devAlloc(c, &c->dnA, n3); if (rc != PT_OK) return rc; }
+    if (!c->dnB) { int rc = devAlloc(c, &c->dnB, n3); if (rc != PT_OK) return rc; }
+    const int W = c->cam.resolution[0], H = c->cam.resolution[1];
+    ptl_average(c->stream, c->imageSum, samples, n3, c->dnA);
+    float* a = c->dnA;
+    float* b = c->dnB;
+    float sc = sigma_color;
+    for (int l = 0; l < levels; ++l) {
+        ptl_atrous(c->stream, a, sigma_normal > 0.0f ? c->gNormals : nullptr, sigma_albedo > 0.0f ? c->gAlbedo : nullptr, W, H, 1 << l,
+                   1.0f / (sc * sc), sigma_normal > 0.0f ? 1.0f / (sigma_normal * sigma_normal) : 0.0f,
+                   sigma_albedo > 0.0f ? 1.0f / (sigma_albedo * sigma_albedo) : 0.0f, b);
+        std::swap(a, b);
+        sc *= 0.5f;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgb, a, n3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
 }
 
 int pt_camera_rays(PtContext* c, int iter, float* origins, float* directions)

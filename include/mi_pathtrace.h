@@ -306,6 +306,20 @@ typedef struct PtLayoutStats {
 } PtLayoutStats;
 int pt_bvh_device_layout(const PtTriangle* triangles, int triangleCount, const PtBvh* bvh, PtLayoutStats* out);
 
+/* Guide buffers and denoising (role of captureNormalsAndAlbedo, src/pathtrace.cu:94-135, and of the denoiser
+ * step of pathtrace(), :2885-2910).
+ * pt_capture_gbuffer: the camera rays of iteration iter through the intersect stage; per pixel the normalised
+ * first-hit normal and the hit material's base colour, zeros where the ray leaves the scene.  Kept on the device
+ * for pt_denoise; copied to the host arrays (W*H*3 floats each) that are not NULL.  Uses the path state, so call
+ * it between traces.
+ * pt_denoise: the reference's OptiX denoiser is closed; this is an open stand-in with the same inputs — an
+ * edge-avoiding a-trous wavelet filter over (running sum / samples): `levels` passes (1..8) of a 5x5 B3-spline
+ * kernel with holes 1, 2, 4, ...; tap weight exp(-(|dc|^2/sc^2 + |dn|^2/sn^2 + |da|^2/sa^2)), sc halving every
+ * pass.  sigma_normal / sigma_albedo <= 0 leave that guide out.  out_rgb: W*H*3 floats on the host. */
+int pt_capture_gbuffer(PtContext* ctx, int iter, float* normals, float* albedo);
+int pt_denoise(PtContext* ctx, float samples, int levels, float sigma_color, float sigma_normal, float sigma_albedo,
+               float* out_rgb);
+
 /* Scene loader (role of Scene::loadFromJSON, src/scene.cpp:570-919, and of
  * the camera set-up in main.cpp:750-769, :788-807).  Returns an owning scene
  * whose PtSceneDesc stays valid until pt_scene_free.  No GPU needed. */

@@ -393,6 +393,12 @@ def test_pathtrace_surface_headless_driver(pt, scenes, orc, gpu_ok, tmp_path):
     png, hdr = str(tmp_path / "img.png"), str(tmp_path / "img.hdr")
     subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", png], timeout=120)
     subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", hdr, "--batch"], timeout=120)
+    dn = str(tmp_path / "dn.pfm")
+    subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", dn, "--denoise"], timeout=120)
+    with open(dn, "rb") as f:
+        f.readline(); f.readline(); f.readline()
+        smooth = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
+    assert np.isfinite(smooth).all() and not np.array_equal(smooth, expect) and abs(float(smooth.mean()) / float(expect.mean()) - 1) < 0.2
     want8 = (np.clip(expect[:, ::-1], 0, 1) * np.float32(255)).astype(np.uint8)
     got8 = pt.decode_png(open(png, "rb").read())
     assert np.array_equal(got8[:, :, :3], want8) and (got8[:, :, 3] == 255).all()
@@ -571,3 +577,73 @@ def test_sparse_launch_form_is_bit_identical(pt, scenes, orc, gpu_ok, monkeypatc
     for it in range(1, 13):
         o.trace(it)
     assert _same_bits(images[0], o.image())
+
+
+def _atrous_reference(img, normals, albedo, levels, sc, sn, sa):
+    """CPU statement of the library's a-trous filter (float64 accumulators; the device works in float32)."""
+    kern = np.array([1 / 16, 1 / 4, 3 / 8, 1 / 4, 1 / 16])
+    cur = img.astype(np.float64)
+    H, W = cur.shape[:2]
+    for l in range(levels):
+        step = 1 << l
+        acc = np.zeros_like(cur)
+        wsum = np.zeros((H, W))
+        for dy in range(-2, 3):
+            for dx in range(-2, 3):
+                oy, ox = dy * step, dx * step
+                ys = slice(max(0, -oy), min(H, H - oy))
+                xs = slice(max(0, -ox), min(W, W - ox))
+                yt = slice(ys.start + oy, ys.stop + oy)
+                xt = slice(xs.start + ox, xs.stop + ox)
+                e = ((cur[yt, xt] - cur[ys, xs]) ** 2).sum(-1) / (sc * sc)
+                if sn > 0:
+                    e = e + ((normals[yt, xt].astype(np.float64) - normals[ys, xs]) ** 2).sum(-1) / (sn * sn)
+                if sa > 0:
+                    e = e + ((albedo[yt, xt].astype(np.float64) - albedo[ys, xs]) ** 2).sum(-1) / (sa * sa)
+                w = kern[dy + 2] * kern[dx + 2] * np.exp(-e)
+                acc[ys, xs] += cur[yt, xt] * w[..., None]
+                wsum[ys, xs] += w
+        cur = acc / wsum[..., None]
+        sc *= 0.5
+    return cur
+
+
+def test_gbuffer_capture_and_denoiser(pt, scenes, orc, gpu_ok):
+    """captureNormalsAndAlbedo (src/pathtrace.cu:94-135): first-hit normal (normalised) and material colour per pixel,
+    bit-exact against the oracle's camera rays + intersect; the a-trous stand-in for the closed denoiser against a
+    CPU statement of the same filter, and it does reduce the error of a noisy render."""
+    sc = scenes.make_scene("dragon", res=(96, 64), depth=6, grid=(40, 41), env_size=(64, 32), tex_size=16)
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc)
+    normals, albedo = tr.capture_gbuffer(3)
+    ro, rd = o.camera_rays(3)
+    h = o.intersect(ro, rd)
+    hit = h["t"] > 0
+    n = h["normal"].astype(np.float32)
+    d = (n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1]) + n[:, 2] * n[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nn = n * (np.float32(1.0) / np.sqrt(d, dtype=np.float32))[:, None]
+    mats = sc.materials()
+    col = np.array([list(m.color) for m in mats], np.float32)
+    want_n = np.where(hit[:, None], nn, np.float32(0)).reshape(64, 96, 3)
+    want_a = np.where(hit[:, None], col[np.clip(h["materialId"], 0, len(mats) - 1)], np.float32(0)).reshape(64, 96, 3)
+    assert _same_bits(normals, want_n) and _same_bits(albedo, want_a)
+    assert 0.2 < hit.mean() < 1.0 and len(np.unique(h["materialId"][hit])) >= 3
+    # denoise 4 spp against a 256 spp render of the same scene
+    tr.set_option(pt.PT_OPT_BATCH, 64)
+    tr.trace_range(1, 5)
+    noisy = tr.image() / np.float32(4)
+    for guides in ((0.0, 0.0), (0.35, 0.25)):
+        got = tr.denoise(4, levels=4, sigma_color=0.8, sigma_normal=guides[0], sigma_albedo=guides[1])
+        ref = _atrous_reference(noisy, normals, albedo, 4, 0.8, guides[0], guides[1])
+        assert np.allclose(got, ref, rtol=2e-4, atol=2e-5), float(np.abs(got - ref).max())
+    tr.clear()
+    tr.trace_range(1, 257)
+    clean = tr.image() / np.float32(256)
+    tr.upload_image(noisy * np.float32(4))
+    strong = tr.denoise(4, levels=5, sigma_color=4.0, sigma_normal=0.35, sigma_albedo=0.25)
+    err = lambda a: float(np.mean(np.abs(np.clip(a, 0, 2) - np.clip(clean, 0, 2))))
+    print("mean abs error: noisy %.4f, filtered %.4f" % (err(noisy), err(strong)))
+    assert err(strong) < 0.85 * err(noisy), (err(strong), err(noisy))
+    with pytest.raises(pt.PtError):
+        pt.Tracer(sc).denoise(4)            # guides wanted, nothing captured
