@@ -876,6 +876,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     }
 
     SceneView& V = c->view;
+    V.cameraOrigin = 0; V.traceDepth = c->traceDepth; memcpy(V.camPos, c->cam.position, sizeof(V.camPos));     /* set per call in traceBatch */
     V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.leafOfOrig = dLeaf;
     V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond;
     V.numGeoms = d->geomCount; V.numMaterials = d->materialCount; V.numTextures = d->textureCount; V.numLights = (int)lights.size();
@@ -912,6 +913,9 @@ static int traceBatch(PtContext* c, Batch bt)
     SceneView V = c->view;
     V.useBvh = c->useBvh;
     V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
+    V.cameraOrigin = 1;
+    V.traceDepth = c->traceDepth;
+    memcpy(V.camPos, c->cam.position, sizeof(V.camPos));
     const bool count = c->counters != 0;
     uint32_t* ctr = c->workCtr;
     HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));

@@ -116,9 +116,11 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
         Ray r; r.o = f3(cam.position); r.d = dir;
         cand = mayHitBvhMeshes(S, r, __builtin_inff());
     }
-    st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
     st.rayD[index] = make_float4(dir.x, dir.y, dir.z, __int_as_float(cand ? 1 : 0));
-    st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
+    if (!S.cameraOrigin) {      /* otherwise bounce 0 takes these from the scene view (loadRayO / loadCol) */
+        st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
+        st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
+    }
     }
     if (S.numBvhMeshes > 0) {
         const int at = blockAppendIndex(cand, traceCount + blockIdx.y * kCtrStride, s_tmp);
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                         fetch = false;
                         if (MODE == TRACE_CLOSEST) {
                             pix = st.traceQueue[sidx];
-                            float4 o = st.rayO[pix], d = st.rayD[pix];
+                            float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix];
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
                         } else {
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
         int key = 0;
         if (active) {
             const int pix = bounce == 0 ? slot : q.q0[slot];
-            float4 o = st.rayO[pix], d = st.rayD[pix];
+            float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix];
             Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
             Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
             if (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0) {      /* the ray was filed for traversal */
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         bool cand = false;
         if (active) {
             pix = (!sortOn && bounce == 0) ? slot : queue[slot];
-            float4 o = st.rayO[pix], d = st.rayD[pix], c = st.col[pix];
+            float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix], c = loadCol(S, st.col, pix, bounce);
             float4 ha = st.hitA[pix], hb = st.hitB[pix];
             Path p;
             p.o = f3(o.x, o.y, o.z); p.d = f3(d.x, d.y, d.z); p.color = f3(c.x, c.y, c.z);

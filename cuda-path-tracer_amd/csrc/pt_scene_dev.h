@@ -71,7 +71,25 @@ struct SceneView {
     float envTotalPower;
     int numBuckets;                 /* numMaterials + 1 */
     int numBvhMeshes;               /* mesh geoms traversed through their BVH (0 when BVH use is off) */
+    /* Primary rays share their origin, throughput (1,1,1) and bounce budget: when cameraOrigin is set the camera
+     * kernel does not store them and the stages of bounce 0 take them from here (a third of the bytes a primary
+     * path moves).  Off for the stage hooks, whose rays come from the caller. */
+    int cameraOrigin;
+    int traceDepth;
+    float camPos[3];
 };
+
+/* origin record (xyz, previous-bounce-was-specular flag) and colour record (throughput, remaining bounces) of a path */
+PT_DEV float4 loadRayO(const SceneView& S, const float4* rayO, int pix, int bounce)
+{
+    if (bounce == 0 && S.cameraOrigin) return make_float4(S.camPos[0], S.camPos[1], S.camPos[2], __int_as_float(0));
+    return rayO[pix];
+}
+PT_DEV float4 loadCol(const SceneView& S, const float4* col, int pix, int bounce)
+{
+    if (bounce == 0 && S.cameraOrigin) return make_float4(1.0f, 1.0f, 1.0f, __int_as_float(S.traceDepth));
+    return col[pix];
+}
 
 /* Several iterations ("a batch") run through the same launches, one grid row (blockIdx.y) each.
  * Every iteration owns a full copy of the path state and of the queues, so slot numbering, sort
