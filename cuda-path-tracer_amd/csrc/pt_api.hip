@@ -876,7 +876,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     }
 
     SceneView& V = c->view;
-    V.cameraOrigin = 0; V.traceDepth = c->traceDepth; memcpy(V.camPos, c->cam.position, sizeof(V.camPos));     /* set per call in traceBatch */
+    V.cameraOrigin = 0; V.leanHits = 0; V.traceDepth = c->traceDepth; memcpy(V.camPos, c->cam.position, sizeof(V.camPos));     /* set per call in traceBatch */
     V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.leafOfOrig = dLeaf;
     V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond;
     V.numGeoms = d->geomCount; V.numMaterials = d->materialCount; V.numTextures = d->textureCount; V.numLights = (int)lights.size();
@@ -914,6 +914,7 @@ static int traceBatch(PtContext* c, Batch bt)
     V.useBvh = c->useBvh;
     V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
     V.cameraOrigin = 1;
+    V.leanHits = 1;
     V.traceDepth = c->traceDepth;
     memcpy(V.camPos, c->cam.position, sizeof(V.camPos));
     const bool count = c->counters != 0;

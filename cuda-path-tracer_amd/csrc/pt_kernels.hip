@@ -271,8 +271,10 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     fetch = false;
                 } else if (MODE == TRACE_CLOSEST) {
                     st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
-                    st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
-                    st.hitTri[pix] = best.tri;
+                    if (best.t > 0.0f || !S.leanHits) {    /* the same test the readers apply */
+                        st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
+                        st.hitTri[pix] = best.tri;
+                    }
                 } else {
                     /* settle the path colour, then the image add the shade stage held back */
                     float4 c = st.col[pix];
@@ -397,10 +399,13 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
             Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
             Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
             if (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0) {      /* the ray was filed for traversal */
-                float4 ha = st.hitA[pix], hb = st.hitB[pix];
+                float4 ha = st.hitA[pix];
                 best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
-                best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
-                best.tri = st.hitTri[pix];
+                if (ha.x > 0.0f || !S.leanHits) {       /* the rest of a miss record is what best already holds */
+                    float4 hb = st.hitB[pix];
+                    best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
+                    best.tri = st.hitTri[pix];
+                }
             }
             const bool traced = best.geom >= 0 || (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0);
             const int meshGeom = best.geom;
@@ -569,7 +574,9 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         if (active) {
             pix = (!sortOn && bounce == 0) ? slot : queue[slot];
             float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix], c = loadCol(S, st.col, pix, bounce);
-            float4 ha = st.hitA[pix], hb = st.hitB[pix];
+            float4 ha = st.hitA[pix];
+            float4 hb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (ha.x > 0.0f) hb = st.hitB[pix];        /* material and uv only matter for a hit */
             Path p;
             p.o = f3(o.x, o.y, o.z); p.d = f3(d.x, d.y, d.z); p.color = f3(c.x, c.y, c.z);
             p.remaining = __float_as_int(c.w);

@@ -75,6 +75,10 @@ struct SceneView {
      * kernel does not store them and the stages of bounce 0 take them from here (a third of the bytes a primary
      * path moves).  Off for the stage hooks, whose rays come from the caller. */
     int cameraOrigin;
+    /* A miss is fully described by its distance (-1): with leanHits set the traversal writes only the first 16 bytes
+     * of a miss record and the later stages do not read the rest (set while tracing; the stage hooks export whole
+     * records and leave it off). */
+    int leanHits;
     int traceDepth;
     float camPos[3];
 };
