@@ -283,9 +283,11 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                         c.x = v.x; c.y = v.y; c.z = v.z;
                         st.col[pix] = c;
                     }
-                    if (__float_as_int(c.w) == 0) {
+                    if (__float_as_int(c.w) <= 0) {
+                        /* the path's one contribution, see k_shade (nothing for a path that ended below zero) */
+                        const bool counts = __float_as_int(c.w) == 0;
                         float* im = st.image + 3 * (size_t)pix;
-                        im[0] += c.x; im[1] += c.y; im[2] += c.z;
+                        im[0] = counts ? c.x : 0.0f; im[1] = counts ? c.y : 0.0f; im[2] = counts ? c.z : 0.0f;
                     }
                 }
             }
@@ -412,8 +414,10 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
             foldInlineGeoms<COUNT>(S, r, best, cnt);
             if (!traced || best.geom != meshGeom) {       /* the traversal's record stands unless an inline geom is closer */
                 st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
-                st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
-                st.hitTri[pix] = best.tri;
+                if (best.t > 0.0f || !S.leanHits) {
+                    st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
+                    st.hitTri[pix] = best.tri;
+                }
             }
             /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */
             key = (best.t > 0.0f) ? best.mat : (numBuckets - 1);
@@ -592,10 +596,14 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
             }
             if (alive || sq.pending) {
                 st.col[pix] = make_float4(p.color.x, p.color.y, p.color.z, __int_as_float(p.remaining));
-            } else if (p.remaining == 0) {
-                /* gatherTerminatedPaths (src/pathtrace.cu:2641-2653): one path per pixel, so a plain add */
+            } else {
+                /* gatherTerminatedPaths (src/pathtrace.cu:2641-2653).  A pixel has one path per iteration and every path
+                 * ends exactly once — here, in the shadow traversal that settles its last colour, or in the final
+                 * gather — so its contribution is a plain store into this iteration's contribution image, and that
+                 * image is rewritten completely by every iteration (nothing to clear, no read-modify-write). */
                 float* im = st.image + 3 * (size_t)pix;
-                im[0] += p.color.x; im[1] += p.color.y; im[2] += p.color.z;
+                const bool counts = p.remaining == 0;       /* a path that ended below zero adds nothing (the reference gathers == 0 only) */
+                im[0] = counts ? p.color.x : 0.0f; im[1] = counts ? p.color.y : 0.0f; im[2] = counts ? p.color.z : 0.0f;
             }
             queue[slot] = alive ? pix : (-1 - pix);
         }
@@ -694,7 +702,7 @@ __global__ void __launch_bounds__(kBlock) k_final_gather(PathState st, Queues q,
         const int pix = q.q0[slot];
         float4 c = st.col[pix];
         float* im = st.image + 3 * (size_t)pix;
-        im[0] += c.x; im[1] += c.y; im[2] += c.z;
+        im[0] = c.x; im[1] = c.y; im[2] = c.z;
     }
 }
 
@@ -737,22 +745,20 @@ __global__ void __launch_bounds__(64) k_finish(Queues q0, int depth, int batch, 
 }
 
 /* image += contribution of iteration 0, then 1, ... : the order one-iteration-at-a-time accumulation
- * would add them in (at most one contribution per pixel and iteration); contributions are re-zeroed */
-__global__ void __launch_bounds__(kBlock) k_accumulate(float* image, float* partial, size_t n3, int batch)
+ * would add them in (exactly one contribution per pixel and iteration, stored by the stage that ends the path) */
+__global__ void __launch_bounds__(kBlock) k_accumulate(float* image, const float* partial, size_t n3, int batch)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n3) return;
     float acc = image[i];
     for (int k = 0; k < batch; ++k) {
-        float v = partial[(size_t)k * n3 + i];
-        acc += v;
-        partial[(size_t)k * n3 + i] = 0.0f;
+        acc += partial[(size_t)k * n3 + i];
     }
     image[i] = acc;
 }
 
 /* the same, four floats per lane (16-byte accesses); n4 = n3 / 4, for 16-byte aligned buffers with n3 % 4 == 0 */
-__global__ void __launch_bounds__(kBlock) k_accumulate4(float4* image, float4* partial, size_t n4, int batch)
+__global__ void __launch_bounds__(kBlock) k_accumulate4(float4* image, const float4* partial, size_t n4, int batch)
 {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n4) return;
@@ -760,7 +766,6 @@ __global__ void __launch_bounds__(kBlock) k_accumulate4(float4* image, float4* p
     for (int k = 0; k < batch; ++k) {
         float4 v = partial[(size_t)k * n4 + i];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        partial[(size_t)k * n4 + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     image[i] = acc;
 }
