@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
  * closest of all geoms is order-independent once equal distances go to the lower geom index, which
  * is what the reference's in-order strict '<' loop yields. */
 #ifndef PT_REFILL
-#define PT_REFILL 32
+#define PT_REFILL 24
 #endif
 #ifndef PT_TRACE_MINWAVES
 #define PT_TRACE_MINWAVES 4
