@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
     /* work list of the first closest-hit traversal (see k_cull); the verdict travels with the ray (rayD.w) */
     if (S.numBvhMeshes > 0) {
         Ray r; r.o = f3(cam.position); r.d = dir;
-        cand = mayHitBvhMeshes(S, r, __builtin_inff());
+        cand = mayHitBvhMeshes(S, r, __builtin_inff(), true);
     }
     st.rayD[index] = make_float4(dir.x, dir.y, dir.z, __int_as_float(cand ? 1 : 0));
     if (!S.cameraOrigin) {      /* otherwise bounce 0 takes these from the scene view (loadRayO / loadCol) */
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kBlock) k_cull(SceneView S, PathState st, Queu
         pix = bounce == 0 ? slot : q.q0[slot];
         float4 o = st.rayO[pix], d = st.rayD[pix];
         Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
-        cand = mayHitBvhMeshes(S, r, __builtin_inff());
+        cand = mayHitBvhMeshes(S, r, __builtin_inff(), true);
         st.rayD[pix] = make_float4(d.x, d.y, d.z, __int_as_float(cand ? 1 : 0));
     }
     const int idx = blockAppendIndex(cand, workCount + blockIdx.y * kCtrStride, s_tmp);
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
             alive = p.remaining > 0;
             if (alive) {
                 /* the surviving path's new ray goes on the work list of the next closest-hit traversal if it can hit a mesh */
-                if (nextTraceCount) { Ray nr; nr.o = p.o; nr.d = p.d; cand = mayHitBvhMeshes(S, nr, __builtin_inff()); }
+                if (nextTraceCount) { Ray nr; nr.o = p.o; nr.d = p.d; cand = mayHitBvhMeshes(S, nr, __builtin_inff(), true); }
                 st.rayO[pix] = make_float4(p.o.x, p.o.y, p.o.z, __int_as_float(p.prevSpecular ? 1 : 0));
                 st.rayD[pix] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(cand ? 1 : 0));
             }

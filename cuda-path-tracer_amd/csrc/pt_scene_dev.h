@@ -517,10 +517,41 @@ PT_DEV float inlineOccluderDistance(const SceneView& S, const DGeom& g, const Ra
     return -1.0f;
 }
 
-/* Conservative pre-test against the padded world boxes of the BVH meshes: false only when the ray
- * (up to distance maxDist along it, in units of |d|) certainly misses all of them.  Every comparison
- * is false on NaN and the min/max ignore a NaN operand, so odd rays are kept. */
-PT_DEV bool mayHitBvhMeshes(const SceneView& S, const Ray& r, float maxDist)
+/* The traversal's first step, taken ahead of time: true when the ray fails all four child boxes of the mesh's
+ * root node, with the arithmetic travStep uses for them (same loads, same operations, closest distance still at
+ * its initial value).  Such a ray leaves the traversal empty-handed after that one step, so it need not be queued.
+ * Rays outside the fast form (a non-finite origin or reciprocal direction) are kept. */
+PT_DEV bool failsRootNode(const SceneView& S, const DGeom& g, const Ray& r)
+{
+    MeshTrav tv;
+    travInit(g, r, tv);
+    if (!tv.fast) return false;
+    const F3 lo = tv.lo, invDir = tv.invDir;
+    const char* base = (const char*)S.nodes;
+    const uint32_t off = (uint32_t)tv.nodeStart * 128u;
+    const uint32_t exitOff = off + 48u;
+    const float4 nX = *(const float4*)(base + (off + tv.selX));
+    const float4 nY = *(const float4*)(base + (off + tv.selY) + 16);
+    const float4 nZ = *(const float4*)(base + (off + tv.selZ) + 32);
+    const float4 fX = *(const float4*)(base + (exitOff - tv.selX));
+    const float4 fY = *(const float4*)(base + (exitOff - tv.selY) + 16);
+    const float4 fZ = *(const float4*)(base + (exitOff - tv.selZ) + 32);
+    bool any = false;
+#define PT_CHILD_ROOT(C)                                                                            \
+    {                                                                                                \
+        float tMin = __builtin_fmaxf(__builtin_fmaxf((nX.C - lo.x) * invDir.x, (nY.C - lo.y) * invDir.y), (nZ.C - lo.z) * invDir.z); \
+        float tMax = __builtin_fminf(__builtin_fminf((fX.C - lo.x) * invDir.x, (fY.C - lo.y) * invDir.y), (fZ.C - lo.z) * invDir.z); \
+        any = any || ((tMax >= tMin && tMax >= 0.0f) && !(tMin > tv.closestT));                      \
+    }
+    PT_CHILD_ROOT(x) PT_CHILD_ROOT(y) PT_CHILD_ROOT(z) PT_CHILD_ROOT(w)
+#undef PT_CHILD_ROOT
+    return !any;
+}
+
+/* Pre-test of a ray against the BVH meshes: false only when the ray (up to distance maxDist along it, in units
+ * of |d|) certainly misses all of them.  First the padded world box of a mesh — every comparison is false on NaN
+ * and the min/max ignore a NaN operand, so odd rays are kept — then, for rays that pass it, the mesh's root node. */
+PT_DEV bool mayHitBvhMeshes(const SceneView& S, const Ray& r, float maxDist, bool rootTest = false)
 {
     const F3 inv = 1.0f / r.d;
     for (int i = 0; i < S.numGeoms; ++i) {
@@ -532,7 +563,7 @@ PT_DEV bool mayHitBvhMeshes(const SceneView& S, const Ray& r, float maxDist)
         float tMin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
         float tMax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
         const bool miss = (tMax < tMin) || (tMax < 0.0f) || (tMin > maxDist);
-        if (!miss) return true;
+        if (!miss && !(rootTest && failsRootNode(S, g, r))) return true;
     }
     return false;
 }
