@@ -30,6 +30,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <iterator>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -208,6 +209,28 @@ PtMaterial parseMaterial(const ptjson::Value& p)
     return m;
 }
 
+/* An environment map from a Radiance .hdr file, or from a PNG or JPEG file the way stbi_loadf (src/scene.cpp:790)
+ * turns 8-bit images into floats: three colour components, each pow(v / 255, 2.2) evaluated in double. */
+bool loadRadianceHdr(const std::string& path, std::vector<float>& rgb, int& W, int& H);
+bool loadEnvironmentImage(const std::string& path, std::vector<float>& rgb, int& W, int& H)
+{
+    if (loadRadianceHdr(path, rgb, W, H)) return true;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> px;
+    std::string why;
+    const bool png = bytes.size() >= 8 && memcmp(bytes.data(), "\x89PNG\r\n\x1a\n", 8) == 0;
+    const bool jpg = bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8;
+    if (png ? !ptpng::decode(bytes.data(), bytes.size(), px, W, H, why) : jpg ? !ptjpg::decode(bytes.data(), bytes.size(), px, W, H, why) : true) return false;
+    float table[256];
+    for (int v = 0; v < 256; ++v) table[v] = (float)(pow((double)(v / 255.0f), (double)2.2f) * 1.0f);
+    rgb.resize((size_t)W * H * 3);
+    for (size_t i = 0; i < (size_t)W * H; ++i)
+        for (int k = 0; k < 3; ++k) rgb[3 * i + k] = table[px[4 * i + k]];
+    return true;
+}
+
 PtGeom makeGeom(int type, int materialid, const float t[3], const float r[3], const float s[3])
 {
     PtGeom g;
@@ -368,7 +391,8 @@ int pt_scene_load(const char* json_path, PtScene** out)
                 if (file.size() > 1 && file[0] != '/' && file[1] != ':') full = dirOf(json_path) + file;
                 int W = 0, H = 0;
                 std::vector<float> rgb;
-                if (loadRadianceHdr(full, rgb, W, H)) {
+                if (!loadEnvironmentImage(full, rgb, W, H)) S->log += "environment map not loaded: " + full + "\n";
+                else {
                     float intensity = e.contains("INTENSITY") ? e.at("INTENSITY").f() : 1.0f;
                     for (auto& v : rgb) v = v * intensity;
                     S->envData.swap(rgb);

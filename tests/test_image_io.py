@@ -104,3 +104,47 @@ def test_writers_report_errors(pt, tmp_path):
         pt.write_png(tmp_path / "x.png", np.zeros((2, 2, 2), np.uint8))
     with pytest.raises(pt.PtError, match="cannot write"):
         pt.write_hdr(tmp_path / "no" / "dir.hdr", np.zeros((2, 2, 3), np.float32))
+
+
+def test_eight_bit_environment_maps_and_missing_files(pt, scenes, tmp_path):
+    """A PNG or JPEG environment map becomes floats the way stbi_loadf makes them (src/scene.cpp:790): three colour
+    components, pow(v / 255, 2.2) evaluated in double, then INTENSITY; a file that cannot be read leaves the scene
+    without an environment map and a line in the log."""
+    import glb_util, jpeg_util
+    rng = np.random.default_rng(9)
+    rgba = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    (tmp_path / "e.png").write_bytes(glb_util.write_png(rgba, 6))
+    grey = rng.integers(0, 256, (16, 24), dtype=np.uint8)
+    jpg, _ = jpeg_util.encode(grey)
+    (tmp_path / "e.jpg").write_bytes(jpg)
+    cam = scenes._camera("x", 2, 1, res=(4, 4))
+    mats = {"a": dict(TYPE="Diffuse", RGB=[1, 1, 1])}
+
+    def load(name, intensity):
+        d = dict(Materials=mats, Camera=cam, Objects=[], EnvironmentMap=dict(FILE=name, INTENSITY=intensity))
+        (tmp_path / "s.json").write_text(json.dumps(d))
+        return pt.Scene(tmp_path / "s.json")
+
+    def floats(v8, intensity):
+        f = np.power((v8.astype(np.float32) / np.float32(255)).astype(np.float64), np.float64(np.float32(2.2))).astype(np.float32)
+        return f * np.float32(intensity)
+
+    sc = load("e.png", 0.5)
+    env = sc.desc.contents.env
+    assert (env.width, env.height, env.enabled) == (7, 5, 1)
+    got = np.frombuffer(C.string_at(env.data, 7 * 5 * 12), np.float32).reshape(5, 7, 3)
+    assert np.array_equal(got, floats(rgba[..., :3], 0.5))
+    assert sc.log == ""
+
+    sc = load("e.jpg", 1.0)
+    env = sc.desc.contents.env
+    assert (env.width, env.height, env.enabled) == (24, 16, 1)
+    got = np.frombuffer(C.string_at(env.data, 24 * 16 * 12), np.float32).reshape(16, 24, 3)
+    px = pt.decode_jpeg(jpg)
+    assert np.array_equal(got, floats(px[..., :3], 1.0))
+    assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+
+    for name in ("nothing.hdr", "s.json"):
+        sc = load(name, 1.0)
+        assert sc.desc.contents.env.enabled == 0
+        assert "environment map not loaded" in sc.log and name in sc.log
