@@ -1,0 +1,13 @@
+#!/bin/bash
+# A copy of the library with other compile-time settings of the kernels, for A/B runs:
+#   tools/build_variant.sh NAME -DPT_LEAF_WAIT=32 ...   ->  variants/libmi_pathtrace_NAME.so   (use with MI_PATHTRACE_LIB)
+set -e
+cd "$(dirname "$0")/../cuda-path-tracer_amd/csrc"
+NAME=$1; shift
+OUT=../../variants
+mkdir -p $OUT
+FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+/opt/rocm/bin/hipcc $FLAGS "$@" -c pt_kernels.hip -o $OUT/pt_kernels_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmi_pathtrace_$NAME.so host/error.o host/scene_host.o host/gltf_load.o host/image_io.o host/bvh_build.o host/pathtrace_shim.o $OUT/pt_kernels_$NAME.o pt_denoise.o pt_api.o
+rm $OUT/pt_kernels_$NAME.o
+echo built $OUT/libmi_pathtrace_$NAME.so
