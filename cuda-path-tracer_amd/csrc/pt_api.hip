@@ -1198,16 +1198,17 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
             Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
             ptl_import_rays(c->stream, c->state, c->queues, dO, dD, m);
             if (V.numBvhMeshes > 0) {
-                ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection);
-                ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, ctr, ctr + 3 * kWorkCtrSection, nullptr);
+                { SpanGuard g(c, ST_INTERSECT); ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection); }
+                { SpanGuard g(c, ST_TRACE); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, c->counters != 0, ctr, ctr + 3 * kWorkCtrSection, c->dc); }
             }
-            ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr, false);
+            { SpanGuard g(c, ST_INTERSECT); ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, c->counters != 0, c->dc, false); }
             ptl_export_hits(c->stream, c->state, m, dH);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(out + first, dH, (size_t)m * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); rc = PT_EHIP; }
+        else resolveSpans(c);
     }
     (void)hipFree(dO); if (dD) (void)hipFree(dD); if (dH) (void)hipFree(dH);
     return rc;

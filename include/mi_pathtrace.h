@@ -263,7 +263,10 @@ void* pt_stream(PtContext* ctx);
 
 /* Parity hook: closest hit of n world-space rays (host arrays of xyz triples)
  * against the uploaded scene, through the same device code the intersect
- * stage runs (computeIntersectionsBVH, src/pathtrace.cu:834-934). */
+ * stage runs (computeIntersectionsBVH, src/pathtrace.cu:834-934), one image's
+ * worth of rays per launch.  With PT_OPT_STAGE_TIMING on, the kernels' device
+ * time is added to msTrace (traversal) and msIntersect (work list, primitives)
+ * of pt_stats; with PT_OPT_COUNTERS on, their box / triangle counts as well. */
 int pt_intersect_rays(PtContext* ctx, const float* origins, const float* directions,
                       int n, PtHit* out);
 
