@@ -32,6 +32,7 @@ WORKLOADS = {
     "cornell": ("cornell", (800, 800), 8, "cornell.json @800x800 depth 8, env map absent (9 primitives, 13 materials)"),
     "chess": ("chess", (1920, 1080), 10, "chess.json @1920x1080 depth 10 (stand-in: 1.5M triangles, 18 textured PBR materials, HDR env)"),
     "sss": ("sss", (1920, 1080), 8, "sss.json @1920x1080 depth 8"),
+    "sss32": ("sss", (1920, 1080), 32, "sss.json @1920x1080 depth 32"),
     "halo": ("halo", (3840, 2160), 8, "halo.json @3840x2160 depth 8 (stand-in: 3.0M triangles, 13 materials, two lights, HDR env)"),
 }
 

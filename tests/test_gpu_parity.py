@@ -168,7 +168,7 @@ def _assert_full_parity(pt, orc, sc, iters, sort=1, lit=True):
 
 @pytest.mark.parametrize("name,res,depth", [("cornell", (128, 128), 8), ("cornell", (97, 61), 12), ("sss", (96, 96), 8),
                                            ("pbr", (96, 96), 8), ("ssaa", (96, 96), 8), ("cornell_orig", (64, 64), 8),
-                                           ("spheres", (64, 64), 8)])
+                                           ("spheres", (64, 64), 8), ("sss", (64, 64), 32), ("cornell", (40, 40), 64)])
 def test_iterations_bit_exact_primitives(pt, scenes, orc, gpu_ok, name, res, depth):
     sc = scenes.make_scene(name, res=res, depth=depth)
     _assert_full_parity(pt, orc, sc, [1, 2, 3, 4, 5], lit=name != "spheres")    # no light and no env map: black

@@ -1,6 +1,6 @@
 #!/bin/bash
 # All workloads of bench.py, one JSON line each into gpurun_out/bench_<workload>.json; stops at the first failure.
-for w in cornell sss dragon chess halo; do
+for w in cornell sss sss32 dragon chess halo; do
     echo "== $w"
     timeout -k 10 500 python bench.py --workload $w --no-cpu-baseline "$@" 2>gpurun_out/bench_$w.err > gpurun_out/bench_$w.json || { tail -5 gpurun_out/bench_$w.err; exit 1; }
     python3 -c "
