@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 
 
-TUNE_GROUPS = 4      # launch groups the library uses to pick its launch shape (one unmeasured, then 1 / 2 / 3 streams)
+TUNE_GROUPS = 5      # launch groups the library uses to pick its launch shape (one unmeasured, then 1 / 2 / 3 streams and one stream alone)
 
 
 def main():
@@ -49,8 +49,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=0,
-                    help="iterations sharing one launch group = one step (1..256); 0 = 128, or fewer so that the path state of a "
-                         "group stays below 100 GB (63 at 3840x2160)")
+                    help="iterations sharing one launch group = one step (1..512); 0 = the largest power of two whose path state "
+                         "stays below 210 GB (512 at 1920x1080, 128 at 3840x2160)")
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -99,13 +99,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    B = args.spp_per_step if args.spp_per_step > 0 else max(8, min(128, int(100e9 // (npix * 190.0))))
-    B = max(1, min(B, 256))
+    # iterations per launch group: every kernel launch ends with the few longest rays of its bounce, a cost per launch
+    # and not per iteration, so groups are as large as 210 GB of path state (about 190 B per pixel and iteration) allow,
+    # in powers of two so that the persistent traversal grid divides evenly over the rows
+    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 190.0 * b <= 210e9)
+    B = max(1, min(B, 512))
 
     def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...; B of them per step
         return 1 + rank + step * B * world
 
-    # ---- untimed: context set-up (the library tries its launch shapes on the first four launch groups of a size and
+    # ---- untimed: context set-up (the library tries its launch shapes on the first five launch groups of a size and
     # keeps the fastest), warmup, then a counted pass over the timed iterations (exact node / triangle counts)
     tr.set_option(pt.PT_OPT_BATCH, B)
     tr.trace_range(it_index(0), it_index(TUNE_GROUPS), world)

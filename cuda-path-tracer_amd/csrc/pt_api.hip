@@ -54,9 +54,9 @@ void ptl_math(hipStream_t s, int fn, const float* a, const float* b, int n, floa
 
 constexpr int kDefaultStreamGroups = 3;
 constexpr int kDefaultBatch = 16;   /* iterations per launch group in pt_trace_range */
-constexpr int kMaxBatch = 256;
+constexpr int kMaxBatch = 512;
 constexpr int kMaxStreamGroups = 8;
-constexpr int kTuneShapes = 3;          /* launch shapes tried: 1, 2, 3 streams */
+constexpr int kTuneShapes = 4;          /* launch shapes tried: 1, 2, 3 streams (1 with the shadow traversal on a side stream), then one stream and nothing beside it */
 constexpr int kTuneMinRows = 12;        /* smaller launch groups stay on one stream */
 /* device work counters, zeroed before every launch group: [section][bounce][batch row] with sections
  * 0 = next entry of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length,
@@ -937,19 +937,22 @@ static int traceBatch(PtContext* c, Batch bt)
      * other groups fill the machine.  With stage timing on everything stays on one stream so that the
      * event-bracketed durations are those of kernels running alone. */
     int groups = 1;                     /* stage timing, or no traversal and so no tails to hide: one stream */
+    int shape = 1;                      /* 1..3: that many streams; kTuneShapes: one stream, shadow traversal in line */
     bool tuning = false;
     if (!c->timing && meshes) {
         if (c->streamsFixed) groups = std::max(1, std::min(c->streamGroups, bt.count / c->rowsPerGroup));
-        else if (bt.count >= kTuneMinRows && count) { if (bt.count == c->tuneRows && c->tuneStage > kTuneShapes) groups = c->tuneChoice; }    /* counted kernels are no measure */
+        else if (bt.count >= kTuneMinRows && count) { if (bt.count == c->tuneRows && c->tuneStage > kTuneShapes) shape = c->tuneChoice; }    /* counted kernels are no measure */
         else if (bt.count >= kTuneMinRows) {
             /* stages: 0 = a first group on one stream, unmeasured (first launches, no live-count hint yet);
-             * 1..kTuneShapes = measure that many streams; then the choice stands until the group size changes */
+             * 1..kTuneShapes = measure that shape; then the choice stands until the group size changes */
             if (bt.count != c->tuneRows) { c->tuneRows = bt.count; c->tuneStage = 0; }
-            if (c->tuneStage == 0) groups = 1;
-            else if (c->tuneStage <= kTuneShapes) { groups = c->tuneStage; tuning = true; }
-            else groups = c->tuneChoice;
+            if (c->tuneStage == 0) shape = 1;
+            else if (c->tuneStage <= kTuneShapes) { shape = c->tuneStage; tuning = true; }
+            else shape = c->tuneChoice;
         }
+        if (!c->streamsFixed) groups = shape == kTuneShapes ? 1 : shape;
     }
+    const bool inlineShadow = shape == kTuneShapes;
     if (tuning) HIP_TRY(hipEventRecord(c->tuneStart, s));
     if (groups > 1) HIP_TRY(hipEventRecord(c->forkEvent, s));
     for (int g = 0; g < groups; ++g) {
@@ -965,7 +968,7 @@ static int traceBatch(PtContext* c, Batch bt)
          * stage and the sort do not look at either.  It therefore runs on a side stream next to them and is
          * joined before the next shade stage (or the final gather) reads colours again: one more kernel whose
          * tail of long rays is covered by other work. */
-        const bool side = meshes && !c->timing && c->shadowOverlap && groups == 1;      /* small launch groups only: more streams than three get in each other's way */
+        const bool side = meshes && !c->timing && c->shadowOverlap && groups == 1 && !inlineShadow;     /* more streams than three get in each other's way */
         hipStream_t ss = side ? c->shadowStreams[g] : gs;
         bool shadowOpen = false;
         for (int b = 0; b < c->traceDepth; ++b) {
@@ -1005,14 +1008,16 @@ static int traceBatch(PtContext* c, Batch bt)
         HIP_TRY(hipEventSynchronize(c->tuneEnd));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->tuneStart, c->tuneEnd));
-        c->tuneMs[groups] = ms;
-        if (groups == kTuneShapes) {
-            /* more streams only when they pay: the fewest streams within 2 % of the fastest shape */
+        c->tuneMs[shape] = ms;
+        if (shape == kTuneShapes) {
+            /* the faster of the two one-stream shapes, and more streams only when they pay: the fewest streams within
+             * 2 % of the fastest shape */
             float best = c->tuneMs[1];
             for (int g = 2; g <= kTuneShapes; ++g) best = std::min(best, c->tuneMs[g]);
-            c->tuneChoice = 1;
-            while (c->tuneChoice < kTuneShapes && c->tuneMs[c->tuneChoice] > 1.02f * best) c->tuneChoice++;
-            if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] launch shape for groups of %d: %d stream(s) (%.2f / %.2f / %.2f ms)\n", bt.count, c->tuneChoice, c->tuneMs[1], c->tuneMs[2], c->tuneMs[3]);
+            const int order[3] = { c->tuneMs[kTuneShapes] < c->tuneMs[1] ? kTuneShapes : 1, 2, 3 };
+            c->tuneChoice = order[2];
+            for (int k = 0; k < 3; ++k) if (c->tuneMs[order[k]] <= 1.02f * best) { c->tuneChoice = order[k]; break; }
+            if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] launch shape for groups of %d: %d (1-3 streams: %.2f / %.2f / %.2f ms, one stream with the shadow traversal in line: %.2f ms)\n", bt.count, c->tuneChoice, c->tuneMs[1], c->tuneMs[2], c->tuneMs[3], c->tuneMs[4]);
         }
     }
     const bool tunePhase = !c->timing && meshes && !c->streamsFixed && !count && bt.count >= kTuneMinRows && c->tuneStage <= kTuneShapes;

@@ -1,7 +1,7 @@
 /*
  * pt_kernels.hip — gfx950 kernels of the wavefront loop and their launchers.
  *
- * A launch group holds up to 256 iterations (= samples per pixel), one grid row each; per bounce b
+ * A launch group holds up to 512 iterations (= samples per pixel), one grid row each; per bounce b
  * every row runs:
  *   k_trace<closest>  persistent BVH traversal over the rays filed for it (by k_camera for b = 0, by
  *                     k_shade afterwards): closest mesh hit by pixel

@@ -215,7 +215,7 @@ enum PtOption {
     PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
     PT_OPT_USE_GRAPH = 5,        /* reserved (hipGraph replay); accepted, no effect */
     PT_OPT_BATCH = 6             /* iterations that share one launch group in
-                                    pt_trace_range (default 16, at most 256); results
+                                    pt_trace_range (default 16, at most 512); results
                                     do not depend on it                              */
 };
 
@@ -235,9 +235,11 @@ int pt_trace(PtContext* ctx, int iter);
  * PT_OPT_BATCH iterations form a launch group that runs through the same kernel
  * launches (each iteration with its own path state and queues, so results equal one
  * pt_trace call per iteration, bit for bit); a group runs on one to three streams
- * internally and is joined on the context's stream: the first four groups of a size
- * (12 iterations or more) try the shapes, each of those calls ends with a wait, and the
- * fastest is kept (environment PT_STREAMS, 1..8, fixes the count instead). */
+ * internally and is joined on the context's stream: the first five groups of a size
+ * (12 iterations or more) try the shapes (one, two, three streams, and one stream with
+ * the shadow traversal in line instead of beside the next bounce), each of those calls
+ * ends with a wait, and the fewest streams within 2 % of the fastest shape are kept
+ * (environment PT_STREAMS, 1..8, fixes the count instead). */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE
