@@ -1011,12 +1011,12 @@ static int traceBatch(PtContext* c, Batch bt)
         c->tuneMs[shape] = ms;
         if (shape == kTuneShapes) {
             /* the faster of the two one-stream shapes, and more streams only when they pay: the fewest streams within
-             * 2 % of the fastest shape */
+             * 3 % of the fastest shape (a shape's time varies by 1-2 % from group to group, more so with several streams) */
             float best = c->tuneMs[1];
             for (int g = 2; g <= kTuneShapes; ++g) best = std::min(best, c->tuneMs[g]);
             const int order[3] = { c->tuneMs[kTuneShapes] < c->tuneMs[1] ? kTuneShapes : 1, 2, 3 };
             c->tuneChoice = order[2];
-            for (int k = 0; k < 3; ++k) if (c->tuneMs[order[k]] <= 1.02f * best) { c->tuneChoice = order[k]; break; }
+            for (int k = 0; k < 3; ++k) if (c->tuneMs[order[k]] <= 1.03f * best) { c->tuneChoice = order[k]; break; }
             if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] launch shape for groups of %d: %d (1-3 streams: %.2f / %.2f / %.2f ms, one stream with the shadow traversal in line: %.2f ms)\n", bt.count, c->tuneChoice, c->tuneMs[1], c->tuneMs[2], c->tuneMs[3], c->tuneMs[4]);
         }
     }

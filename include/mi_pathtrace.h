@@ -238,7 +238,7 @@ int pt_trace(PtContext* ctx, int iter);
  * internally and is joined on the context's stream: the first five groups of a size
  * (12 iterations or more) try the shapes (one, two, three streams, and one stream with
  * the shadow traversal in line instead of beside the next bounce), each of those calls
- * ends with a wait, and the fewest streams within 2 % of the fastest shape are kept
+ * ends with a wait, and the fewest streams within 3 % of the fastest shape are kept
  * (environment PT_STREAMS, 1..8, fixes the count instead). */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
