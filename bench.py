@@ -102,7 +102,8 @@ def main():
     # iterations per launch group: every kernel launch ends with the few longest rays of its bounce, a cost per launch
     # and not per iteration, so groups are as large as 210 GB of path state (about 190 B per pixel and iteration) allow,
     # in powers of two so that the persistent traversal grid divides evenly over the rows
-    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 190.0 * b <= 210e9)
+    budget = min(210e9, 0.8 * torch.cuda.mem_get_info()[0])       # never more than four fifths of what is free now
+    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 190.0 * b <= budget)
     B = max(1, min(B, 512))
 
     def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...; B of them per step
@@ -110,7 +111,20 @@ def main():
 
     # ---- untimed: context set-up (the library tries its launch shapes on the first five launch groups of a size and
     # keeps the fastest), warmup, then a counted pass over the timed iterations (exact node / triangle counts)
-    tr.set_option(pt.PT_OPT_BATCH, B)
+    while True:
+        try:
+            tr.set_option(pt.PT_OPT_BATCH, B)         # allocates the path state of B iterations
+            break
+        except pt.PtError:
+            if args.spp_per_step > 0 or B <= 8:
+                raise
+            B //= 2                                   # a GPU with less free memory than planned for: smaller groups
+    if world > 1:                                     # every rank uses the same group size (it fixes the iteration indices)
+        t = torch.tensor([B], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != B:
+            B = int(t.item())
+            tr.set_option(pt.PT_OPT_BATCH, B)
     tr.trace_range(it_index(0), it_index(TUNE_GROUPS), world)
     barrier()
     tr.clear()
