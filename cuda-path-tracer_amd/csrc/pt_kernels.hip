@@ -412,7 +412,9 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
             const bool traced = best.geom >= 0 || (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0);
             const int meshGeom = best.geom;
             foldInlineGeoms<COUNT>(S, r, best, cnt);
-            if (!traced || best.geom != meshGeom) {       /* the traversal's record stands unless an inline geom is closer */
+            /* the traversal's record stands unless an inline geom is closer; with the sort on, a miss needs no record
+             * at all: the shade stage knows the misses by their place in the sorted order */
+            if ((!traced || best.geom != meshGeom) && !(sortOn && !(best.t > 0.0f))) {
                 st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
                 if (best.t > 0.0f || !S.leanHits) {
                     st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
@@ -566,6 +568,9 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     int vb = (int)blockIdx.x;                   /* SPARSE: bounded grid, see k_prims */
     if ((uint32_t)(vb * kBlock) >= n) return;
     int* queue = sortOn ? q.q1 : q.q0;
+    /* sorted order: the misses are the last bucket, and its first slot is the scanned histogram entry of that bucket's
+     * first workgroup — their hit records (distance -1, nothing else read) are not fetched */
+    const uint32_t missStart = sortOn ? (uint32_t)q.blockHist[(size_t)(S.numBuckets - 1) * q.numBlocks] : 0xffffffffu;
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
     do {
         const int slot = vb * kBlock + tid;
@@ -578,7 +583,8 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         if (active) {
             pix = (!sortOn && bounce == 0) ? slot : queue[slot];
             float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix], c = loadCol(S, st.col, pix, bounce);
-            float4 ha = st.hitA[pix];
+            float4 ha = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+            if ((uint32_t)slot < missStart) ha = st.hitA[pix];
             float4 hb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (ha.x > 0.0f) hb = st.hitB[pix];        /* material and uv only matter for a hit */
             Path p;
