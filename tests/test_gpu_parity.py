@@ -271,6 +271,30 @@ def test_batched_iterations_bit_exact(pt, scenes, orc, gpu_ok):
     assert _same_bits(tr.image(), o.image())
 
 
+def test_launch_shapes_and_largest_groups_bit_exact(pt, scenes, orc, gpu_ok):
+    """Groups of 12 iterations or more go through the library's launch-shape trial (one, two, three streams, one stream
+    with the shadow traversal in line, then the kept shape), and a group may hold up to 512 iterations: the sum is
+    the one-iteration-at-a-time result whatever the shape and the group size."""
+    sc = scenes.make_scene("dragon", res=(32, 24), depth=6, grid=(24, 25), env_size=(64, 32), tex_size=16)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    sums = {}
+    for it in range(1, 521):
+        o.trace(it)
+        if it in (112, 520):
+            sums[it] = o.image().copy()
+    tr = pt.Tracer(sc)
+    tr.set_option(pt.PT_OPT_BATCH, 16)
+    tr.trace_range(1, 113)                      # seven groups of 16: unmeasured, four shapes, two with the kept one
+    assert _same_bits(tr.image(), sums[112])
+    tr = pt.Tracer(sc)
+    tr.set_option(pt.PT_OPT_BATCH, 512)
+    tr.trace_range(1, 521)                      # one group of 512 and one of 8
+    assert _same_bits(tr.image(), sums[520])
+    assert tr.stats().pathBounces == o.stats().pathBounces
+    with pytest.raises(pt.PtError):
+        tr.set_option(pt.PT_OPT_BATCH, 513)
+
+
 def test_depth_one_and_tiny_images(pt, scenes, orc, gpu_ok):
     for res, depth in (((1, 1), 8), ((3, 2), 1), ((257, 1), 2), ((16, 16), 1)):
         sc = scenes.make_scene("cornell", res=res, depth=depth)
