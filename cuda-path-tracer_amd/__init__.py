@@ -25,6 +25,7 @@ PT_SPHERE, PT_CUBE, PT_GLTF_MESH = 0, 1, 2
 PT_DIFFUSE, PT_SPECULAR, PT_REFRACTIVE, PT_PBR, PT_EMITTING = 0, 1, 2, 3, 4
 PT_OPT_MATERIAL_SORT, PT_OPT_USE_BVH, PT_OPT_STAGE_TIMING, PT_OPT_COUNTERS, PT_OPT_USE_GRAPH, PT_OPT_BATCH = 1, 2, 3, 4, 5, 6
 PT_MAX_DEPTH = 64
+PT_NOALLOC_MAX_RAYS = 262144
 
 
 class PtGeom(C.Structure):
@@ -130,6 +131,7 @@ def _load():
         "pt_reset_stats": (ip, [vp]),
         "pt_stream": (vp, [vp]),
         "pt_intersect_rays": (ip, [vp, vp, vp, ip, vp]),
+        "pt_intersect_rays_noalloc": (ip, [vp, vp, vp, ip, vp]),
         "pt_camera_rays": (ip, [vp, ip, vp, vp]),
         "pt_math_eval": (ip, [ip, ip, vp, vp, ip, vp]),
         "pt_last_error": (C.c_char_p, []),
@@ -457,6 +459,17 @@ class Tracer:
         assert o.shape == d.shape
         out = np.zeros(len(o), dtype=HIT_DTYPE)
         _check(lib.pt_intersect_rays(self._h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data), "pt_intersect_rays")
+        return out
+
+    def intersect_noalloc(self, origins, directions, out=None):
+        """pt_intersect_rays_noalloc: at most PT_NOALLOC_MAX_RAYS rays, staging in the library's static device array."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        if out is None:
+            out = np.zeros(len(o), dtype=HIT_DTYPE)
+        _check(lib.pt_intersect_rays_noalloc(self._h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data),
+               "pt_intersect_rays_noalloc")
         return out
 
     def camera_rays(self, it):

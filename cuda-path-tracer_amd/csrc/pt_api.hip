@@ -68,6 +68,13 @@ enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_TRAC
 
 struct TimedSpan { hipEvent_t a, b; int stage; };
 
+/* Staging memory of pt_intersect_rays_noalloc (ray origins, directions, hit records): part of the code object, so
+ * every GPU the library runs on holds its own copy from load until the process ends.  Host code reaches it only
+ * through the per-device address hipGetSymbolAddress returns (PtContext::staging, resolved in pt_create). */
+static_assert(sizeof(PtHit) == 36, "PtHit layout");
+constexpr size_t kStagingBytes = (size_t)PT_NOALLOC_MAX_RAYS * (12 + 12 + sizeof(PtHit));
+static __device__ __align__(256) unsigned char scratch[kStagingBytes];
+
 struct PtContext {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -76,6 +83,7 @@ struct PtContext {
     Queues queues{};
     DevCounters* dc = nullptr;
     uint32_t* workCtr = nullptr;
+    void* staging = nullptr;            /* this device's copy of `scratch` */
     int bvhMeshGeoms = 0;               /* mesh geoms that own a BVH */
     int streamGroups = 1;               /* streams the rows of a launch group are spread over */
     hipStream_t groupStreams[kMaxStreamGroups] = {};
@@ -751,6 +759,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     int rc = PT_OK;
 #define TRY_RC(x) do { rc = (x); if (rc != PT_OK) { pt_destroy(c); return rc; } } while (0)
 #define TRY_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { pt_set_error("%s failed: %s", #x, hipGetErrorString(e_)); pt_destroy(c); return PT_EHIP; } } while (0)
+    TRY_HIP(hipGetSymbolAddress(&c->staging, HIP_SYMBOL(scratch)));       /* device `device` is current */
     TRY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TRY_HIP(hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->hintEvent, hipEventDisableTiming));
@@ -1176,24 +1185,21 @@ int pt_reset_stats(PtContext* c)
 
 void* pt_stream(PtContext* c) { return c ? (void*)c->stream : nullptr; }
 
-int pt_intersect_rays(PtContext* c, const float* origins, const float* directions, int n, PtHit* out)
+/* the fixed-ray-set hook over staging buffers the caller of this helper owns: rays go through the production
+ * intersect stage in chunks of at most `chunk` (<= one image's worth of paths) */
+static int intersectStaged(PtContext* c, const float* origins, const float* directions, int n, PtHit* out,
+                           float* dO, float* dD, PtHit* dH, int chunk, bool spans)
 {
-    if (!c || n < 0 || (n > 0 && (!origins || !directions || !out))) { pt_set_error("pt_intersect_rays: bad argument"); return PT_EINVAL; }
-    if (n == 0) return PT_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    /* the rays go through the production intersect stage in chunks of one image's worth of paths */
-    const int chunk = std::min(n, c->numPixels);
-    float *dO = nullptr, *dD = nullptr; PtHit* dH = nullptr;
-    HIP_TRY(hipMalloc((void**)&dO, (size_t)chunk * 12));
-    hipError_t e1 = hipMalloc((void**)&dD, (size_t)chunk * 12);
-    hipError_t e2 = hipMalloc((void**)&dH, (size_t)chunk * sizeof(PtHit));
-    int rc = PT_OK;
-    if (e1 != hipSuccess || e2 != hipSuccess) { pt_set_error("pt_intersect_rays: out of device memory"); rc = PT_ENOMEM; }
     SceneView V = c->view;
     V.useBvh = c->useBvh;
     V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
     uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch * kCtrStride;     /* a slot no bounce of a trace uses */
-    for (int first = 0; rc == PT_OK && first < n; first += chunk) {
+    const bool count = c->counters != 0;
+    /* spans (stage timing, launch counts) take HIP events from a pool that grows on demand: only for callers that may allocate */
+    struct MaybeSpan { PtContext* c; int stage; bool on; hipEvent_t a = nullptr;
+        MaybeSpan(PtContext* ctx, int st, bool o) : c(ctx), stage(st), on(o) { if (on) { c->launches[stage]++; if (c->timing) { a = takeEvent(c); (void)hipEventRecord(a, c->stream); } } }
+        ~MaybeSpan() { if (on && c->timing) { hipEvent_t b = takeEvent(c); (void)hipEventRecord(b, c->stream); c->spans.push_back({ a, b, stage }); } } };
+    for (int first = 0; first < n; first += chunk) {
         const int m = std::min(chunk, n - first);
         hipError_t e = hipMemcpyAsync(dO, origins + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
@@ -1203,20 +1209,54 @@ int pt_intersect_rays(PtContext* c, const float* origins, const float* direction
             Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
             ptl_import_rays(c->stream, c->state, c->queues, dO, dD, m);
             if (V.numBvhMeshes > 0) {
-                { SpanGuard g(c, ST_INTERSECT); ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection); }
-                { SpanGuard g(c, ST_TRACE); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, c->counters != 0, ctr, ctr + 3 * kWorkCtrSection, c->dc); }
+                { MaybeSpan g(c, ST_INTERSECT, spans); ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection); }
+                { MaybeSpan g(c, ST_TRACE, spans); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, count, ctr, ctr + 3 * kWorkCtrSection, c->dc); }
             }
-            { SpanGuard g(c, ST_INTERSECT); ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, c->counters != 0, c->dc, false); }
+            { MaybeSpan g(c, ST_INTERSECT, spans); ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, count, c->dc, false); }
             ptl_export_hits(c->stream, c->state, m, dH);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(out + first, dH, (size_t)m * sizeof(PtHit), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); rc = PT_EHIP; }
-        else resolveSpans(c);
+        if (e != hipSuccess) { pt_set_error("pt_intersect_rays: %s", hipGetErrorString(e)); return PT_EHIP; }
+        if (spans) resolveSpans(c);
     }
+    return PT_OK;
+}
+
+int pt_intersect_rays(PtContext* c, const float* origins, const float* directions, int n, PtHit* out)
+{
+    if (!c || n < 0 || (n > 0 && (!origins || !directions || !out))) { pt_set_error("pt_intersect_rays: bad argument"); return PT_EINVAL; }
+    if (n == 0) return PT_OK;
+    if (c->batch < 1) { pt_set_error("pt_intersect_rays: no path state is allocated"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    /* the rays go through the production intersect stage in chunks of one image's worth of paths */
+    const int chunk = std::min(n, c->numPixels);
+    float *dO = nullptr, *dD = nullptr; PtHit* dH = nullptr;
+    HIP_TRY(hipMalloc((void**)&dO, (size_t)chunk * 12));
+    hipError_t e1 = hipMalloc((void**)&dD, (size_t)chunk * 12);
+    hipError_t e2 = hipMalloc((void**)&dH, (size_t)chunk * sizeof(PtHit));
+    int rc = PT_OK;
+    if (e1 != hipSuccess || e2 != hipSuccess) { pt_set_error("pt_intersect_rays: out of device memory"); rc = PT_ENOMEM; }
+    if (rc == PT_OK) rc = intersectStaged(c, origins, directions, n, out, dO, dD, dH, chunk, true);
     (void)hipFree(dO); if (dD) (void)hipFree(dD); if (dH) (void)hipFree(dH);
     return rc;
+}
+
+int pt_intersect_rays_noalloc(PtContext* c, const float* origins, const float* directions, int n, PtHit* out)
+{
+    if (!c || n < 0 || (n > 0 && (!origins || !directions || !out))) { pt_set_error("pt_intersect_rays_noalloc: bad argument"); return PT_EINVAL; }
+    if (n > PT_NOALLOC_MAX_RAYS) { pt_set_error("pt_intersect_rays_noalloc: %d rays exceed the staging array's %d", n, PT_NOALLOC_MAX_RAYS); return PT_ELIMIT; }
+    if (n == 0) return PT_OK;
+    if (c->batch < 1) { pt_set_error("pt_intersect_rays_noalloc: no path state is allocated"); return PT_EINVAL; }
+    if (!c->staging) { pt_set_error("pt_intersect_rays_noalloc: the staging array was not resolved on device %d", c->device); return PT_EHIP; }
+    HIP_TRY(hipSetDevice(c->device));
+    /* origins | directions | hit records, each region a multiple of 256 bytes long */
+    unsigned char* base = (unsigned char*)c->staging;
+    float* dO = (float*)base;
+    float* dD = (float*)(base + (size_t)PT_NOALLOC_MAX_RAYS * 12);
+    PtHit* dH = (PtHit*)(base + (size_t)PT_NOALLOC_MAX_RAYS * 24);
+    return intersectStaged(c, origins, directions, n, out, dO, dD, dH, std::min(n, c->numPixels), false);
 }
 
 int pt_capture_gbuffer(PtContext* c, int iter, float* normals, float* albedo)

@@ -272,6 +272,18 @@ void* pt_stream(PtContext* ctx);
 int pt_intersect_rays(PtContext* ctx, const float* origins, const float* directions,
                       int n, PtHit* out);
 
+/* pt_intersect_rays for callers that cannot allocate (code under HIP graph capture set-up, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results as
+ * pt_intersect_rays; the three staging buffers (origins, directions, hit records) live in a static device array
+ * of PT_NOALLOC_MAX_RAYS * 60 bytes (15 MiB) that every GPU running the library holds until the process ends, so
+ * the call performs no hipMalloc / hipFree and takes no HIP event from the context's pool (stage timing and launch
+ * counts of pt_stats do not see it).  n > PT_NOALLOC_MAX_RAYS returns PT_ELIMIT.  All contexts on one GPU share
+ * the array: calls that overlap on one GPU race.  Pass page-locked host arrays if the HIP runtime's own staging
+ * of pageable copies matters to the caller. */
+#define PT_NOALLOC_MAX_RAYS 262144
+int pt_intersect_rays_noalloc(PtContext* ctx, const float* origins, const float* directions,
+                              int n, PtHit* out);
+
 /* Parity hook: the camera stage alone (generateRayFromCamera,
  * src/pathtrace.cu:694-745): W*H origins and directions to host arrays. */
 int pt_camera_rays(PtContext* ctx, int iter, float* origins, float* directions);
