@@ -21,8 +21,9 @@
  * Arithmetic is in GLM 0.9.6.3's order of operations (xform.h), doubles of the file are narrowed to float
  * where the reference narrows them.
  *
- * Deliberate differences: accessor byteStride is honoured (the reference assumes tightly packed data);
- * the scalars the reference leaves uninitialised in an imported Material (specular exponent, index of
+ *  - a buffer view's byteStride is ignored: attributes and indices are read tightly packed (:363-420), so an
+ *    interleaved file imports the way the reference imports it;
+ * Deliberate differences: the scalars the reference leaves uninitialised in an imported Material (specular exponent, index of
  * refraction, subsurface radius / scale / anisotropy / enabled, src/scene.cpp:96) are 0, 1.5, 0, 0, 0, 0;
  * images that are neither 8-bit PNG nor sequential 8-bit JPEG (16-bit PNG, progressive JPEG, other formats) are
  * skipped with a warning (texture index -1) instead of failing the load.
@@ -182,8 +183,9 @@ bool accessorView(const Doc& d, int index, View& v, std::string& err)
     if (!v.comps || !csize) { err = "unsupported accessor type"; return false; }
     v.count = (size_t)numOr(a, "count", 0);
     size_t elem = csize * v.comps;
-    v.stride = (size_t)numOr(bv, "byteStride", 0);
-    if (v.stride == 0) v.stride = elem;
+    /* elements are read tightly packed from the accessor's start whatever the view's byteStride says: the reference
+     * indexes positions[i * 3], normals[i * 3], texcoords[i * 2] and indices[i] directly (src/scene.cpp:363-420) */
+    v.stride = elem;
     size_t off = (size_t)numOr(bv, "byteOffset", 0) + (size_t)numOr(a, "byteOffset", 0);
     const auto& buf = d.buffers[bi];
     if (v.count && (v.stride < elem || off > buf.size() || (v.count - 1) * v.stride + elem > buf.size() - off)) { err = "accessor reaches past its buffer"; return false; }

@@ -219,6 +219,7 @@ struct Oracle {
     bool anyBvh = false;
     /* options */
     bool sortByMaterial = true, useBvh = true, counters = false;
+    bool scatterRightToLeft = false;    /* ORACLE_OPT_SCATTER_RIGHT_TO_LEFT */
     const MathFns* M = &kLibm;
     /* state */
     std::vector<V3> image;
@@ -967,10 +968,12 @@ void shadePBR(const Oracle& S, PathSegment& path, const Isect& isect, const PtMa
             path.ray.origin = P - n * 0.001f;
         }
         if (roughness > 0.1f && roughness < 0.8f) {
-            /* constructor arguments drawn left to right (x, y, z), as nvcc and clang evaluate them */
-            float sx = rng.u01() - 0.5f;
-            float sy = rng.u01() - 0.5f;
-            float sz = rng.u01() - 0.5f;
+            /* constructor arguments drawn left to right (x, y, z), as nvcc and clang evaluate them; a g++ host build of
+             * the reference draws them right to left (z, y, x) — kept selectable so that both recorded answers of
+             * that build can be reproduced */
+            float sx, sy, sz;
+            if (S.scatterRightToLeft) { sz = rng.u01() - 0.5f; sy = rng.u01() - 0.5f; sx = rng.u01() - 0.5f; }
+            else { sx = rng.u01() - 0.5f; sy = rng.u01() - 0.5f; sz = rng.u01() - 0.5f; }
             V3 scatter = V3(sx, sy, sz) * roughness * 0.2f;
             newDir = normalize(newDir + scatter);
         }
@@ -1449,6 +1452,7 @@ void oracle_set_option(Oracle* o, int option, int value)
     if (option == PT_OPT_MATERIAL_SORT) o->sortByMaterial = value != 0;
     else if (option == PT_OPT_USE_BVH) o->useBvh = value != 0;
     else if (option == PT_OPT_COUNTERS) o->counters = value != 0;
+    else if (option == ORACLE_OPT_SCATTER_RIGHT_TO_LEFT) o->scatterRightToLeft = value != 0;
 }
 void oracle_clear(Oracle* o)
 {

@@ -21,6 +21,10 @@ enum OracleMath {
     ORACLE_MATH_DET = 1     /* det_math.h: bit-identical to the GPU kernels' arithmetic         */
 };
 
+/* oracle-only option, beside the PtOption values: draw the three scatter offsets of the PBR transmission branch
+ * (src/pathtrace.cu:1786-1790, a constructor's argument list) in the order z, y, x, as a g++ host build evaluates it */
+enum { ORACLE_OPT_SCATTER_RIGHT_TO_LEFT = 100 };
+
 Oracle* oracle_create(const PtSceneDesc* scene);
 void oracle_destroy(Oracle* o);
 void oracle_set_math(Oracle* o, int mode);

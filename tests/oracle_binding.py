@@ -7,6 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 MATH_LIBM, MATH_DET = 0, 1
+OPT_SCATTER_RIGHT_TO_LEFT = 100      # oracle-only, see oracle/pt_oracle.h
 FN = dict(sin=0, cos=1, acos=2, atan2=3, exp=4, log=5, pow5=6, div=7, sqrt=8)
 
 _lib = C.CDLL(LIB)

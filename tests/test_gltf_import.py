@@ -139,7 +139,7 @@ def _point(M, p):
     return ((M[0] * p[0] + M[1] * p[1]) + (M[2] * p[2] + M[3] * f32(1)))[:3]
 
 
-def _build_test_glb(tmp_path, name="t.glb", text=None):
+def _build_test_glb(tmp_path, name="t.glb", text=None, interleaved=False):
     rng = np.random.default_rng(7)
     b = G.GlbBuilder()
     tex = b.image_png(G.write_png(_rand((8, 8, 3), 256, 3), 2))
@@ -149,11 +149,16 @@ def _build_test_glb(tmp_path, name="t.glb", text=None):
     b.material(emissiveFactor=[1.0, 2.0, 2.0])
     b.material(alphaMode="MASK", alphaCutoff=0.7, pbrMetallicRoughness=dict(baseColorFactor=[0.5, 0.5, 0.5, 1.0]))
     b.material()
-    # mesh 0: an indexed u16 primitive with interleaved attributes, an indexed u32 primitive with positions only
+    # mesh 0: an indexed u16 primitive with three attributes, an indexed u32 primitive with positions only.  The reference
+    # reads attributes tightly packed whatever the buffer view's byteStride says (src/scene.cpp:363-420), so the
+    # interleaved form of the file only makes sense next to the reference's own loader (tests/test_reference_build.py)
     pos = rng.normal(size=(12, 3)).astype(f32)
     nrm = rng.normal(size=(12, 3)).astype(f32)
     uv = rng.random(size=(12, 2)).astype(f32)
-    a_pos, a_nrm, a_uv = b.interleaved(pos, nrm, uv)
+    if interleaved:
+        a_pos, a_nrm, a_uv = b.interleaved(pos, nrm, uv)
+    else:
+        a_pos, a_nrm, a_uv = b.accessor(pos, "VEC3", 5126), b.accessor(nrm, "VEC3", 5126), b.accessor(uv, "VEC2", 5126)
     idx16 = rng.integers(0, 12, size=18).astype(np.uint16)
     pos2 = rng.normal(size=(9, 3)).astype(f32)
     idx32 = np.concatenate([rng.permutation(9), rng.permutation(9)[:3]]).astype(np.uint32)

@@ -11,10 +11,38 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
 
 
+def _utilhash(a):
+    """src/intersections.h:13-22 on 32-bit unsigned integers"""
+    m = 0xffffffff
+    a = ((a + 0x7ed55d16) + (a << 12)) & m
+    a = ((a ^ 0xc761c23c) ^ (a >> 19)) & m
+    a = ((a + 0x165667b1) + (a << 5)) & m
+    a = ((a + 0xd3a2646c) ^ (a << 9)) & m
+    a = ((a + 0xfd7046c5) + (a << 3)) & m
+    a = ((a ^ 0xb55a4f09) ^ (a >> 16)) & m
+    return a
+
+
+def _stream(it, index, depth, n):
+    """makeSeededRandomEngine (src/pathtrace.cu:138-143) + thrust::minstd_rand + uniform_real_distribution<float>,
+    restated here in Python integers so that the order of the draws does not rest on the oracle alone."""
+    h = _utilhash(((1 << 31) | (depth << 22) | it) & 0xffffffff) ^ _utilhash(index)
+    x = h % 2147483647 or 1
+    out = []
+    for _ in range(n):
+        x = (48271 * x) % 2147483647
+        out.append(np.float32(x - 1) / (np.float32(1.0) + np.float32(2147483645)))
+    return np.asarray(out, np.float32)
+
+
 def test_rng_stream(orc):
     k = KAT["rng"]
     u = orc.rng_u01(k["iter"], k["index"], k["depth"], 4)
-    assert sorted(np.float32(x) for x in k["first_two_u01_as_set"]) == sorted(u[:2].tolist())
+    printed = [np.float32(x) for x in k["first_two_u01_as_printed"]]
+    assert u[:2].tolist() == printed[::-1]          # stream order: see "_order" in the golden file
+    assert np.array_equal(u, _stream(k["iter"], k["index"], k["depth"], 4))
+    for it, index, depth in ((7, 123456, 3), (5000, 1439999, 8), (1, 0, 64)):
+        assert np.array_equal(orc.rng_u01(it, index, depth, 16), _stream(it, index, depth, 16))
     assert np.all((u >= 0) & (u <= 1))
 
 
@@ -67,6 +95,22 @@ def test_cornell_800_live_curve_and_radiance(pt, scenes, orc):
     assert o.stats().pathBounces == k["path_bounces_two_iterations"] == 2 * k["path_bounces_per_spp_mean_of_two_iterations"]
     mean = o.image().reshape(-1, 3).astype(np.float64).mean(0) / 2
     assert np.allclose(mean, k["mean_rgb_per_sample_two_iterations"], atol=6e-7)
+
+
+def test_sss_200_path_bounces_both_evaluation_orders(pt, scenes, orc):
+    """The second whole-loop pin: subsurface scattering, the PBR transmission branch and Russian roulette on
+    scenes/sss.json.  The recorded host builds of the reference differ in one thing, the order in which a constructor's
+    three arguments draw from the stream (left to right under clang / nvcc, right to left under g++): the oracle
+    reproduces both totals."""
+    k = KAT["sss_200x200_depth8_iterations_1_to_4"]
+    sc = scenes.make_scene("sss", res=(200, 200), depth=8)
+    for opt, want in ((0, k["path_bounces_left_to_right"]), (1, k["path_bounces_right_to_left"])):
+        o = orc.Oracle(pt, sc, orc.MATH_LIBM)
+        o.set_option(orc.OPT_SCATTER_RIGHT_TO_LEFT, opt)
+        for it in (1, 2, 3, 4):
+            o.trace(it)
+        assert o.stats().pathBounces == want, (opt, o.stats().pathBounces)
+        o.close()
 
 
 def test_struct_sizes(pt):
