@@ -99,7 +99,8 @@ class PtStats(C.Structure):
                 ("msTrace", C.c_float), ("msShadowTrace", C.c_float),
                 ("launchesTrace", C.c_uint32), ("launchesShadowTrace", C.c_uint32),
                 ("tracedRays", C.c_uint64), ("shadowRays", C.c_uint64),
-                ("boxesTested", C.c_uint64), ("shadeBoxesTested", C.c_uint64)]
+                ("boxesTested", C.c_uint64), ("shadeBoxesTested", C.c_uint64),
+                ("maxStackDepth", C.c_uint32), ("ldsStackEntries", C.c_uint32)]
 
 
 class PtError(RuntimeError):

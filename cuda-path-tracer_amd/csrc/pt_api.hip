@@ -108,7 +108,7 @@ struct PtContext {
      * between two events on the main stream, one blocking wait each) and the rest use the fastest.  PT_STREAMS fixes
      * the shape instead.  Results do not depend on the shape. */
     bool streamsFixed = false;
-    int tuneRows = -1, tuneStage = 0, tuneChoice = 1;
+    int tuneStage = 0, tuneChoice = 1;  /* for full groups of `batch` iterations; reset when the batch size is set */
     float tuneMs[kMaxStreamGroups + 1] = {};
     hipEvent_t tuneStart = nullptr, tuneEnd = nullptr;
     PtCamera cam{};
@@ -152,7 +152,7 @@ int devAlloc(PtContext* c, T** out, size_t count)
 }
 
 template <typename T>
-int batchAlloc(PtContext* c, T** out, size_t count, bool zero)
+int batchAlloc(std::vector<void*>& owned, T** out, size_t count, bool zero)
 {
     *out = nullptr;
     void* p = nullptr;
@@ -161,28 +161,44 @@ int batchAlloc(PtContext* c, T** out, size_t count, bool zero)
         pt_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
         return PT_ENOMEM;
     }
-    c->batchAllocs.push_back(p);
+    owned.push_back(p);
     if (zero && hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { pt_set_error("hipMemset failed"); return PT_EHIP; }
     *out = (T*)p;
     return PT_OK;
 }
 
 /* path state, queues and per-iteration contribution buffers for `batch` iterations in flight
- * (about 116 bytes per pixel and iteration) */
+ * (about 176 bytes per pixel and iteration).  The new buffers replace the old ones only when every allocation
+ * has succeeded; after a failure the context still holds, and keeps using, the state it had.  Path state at the
+ * largest group sizes takes most of the device, so the old buffers are released first when the new ones would not
+ * fit beside them — in that case a failure leaves the context without path state (batch 0), every entry point that
+ * needs it then returns PT_EINVAL, and a later pt_set_option(PT_OPT_BATCH) can allocate again. */
 int allocBatchState(PtContext* c, int batch)
 {
-    for (void* p : c->batchAllocs) (void)hipFree(p);
-    c->batchAllocs.clear();
-    c->batch = 0;
     const size_t N = (size_t)c->numPixels, B = (size_t)batch;
-    PathState& P = c->state;
-    Queues& Q = c->queues;
+    size_t freeB = 0, totalB = 0;
+    const size_t need = N * B * 190;
+    const bool known = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
+    if (known && need > totalB) {       /* cannot fit on this device at all: fail before anything is released */
+        pt_set_error("path state for %d iterations at %d pixels needs about %zu MB, the device has %zu MB", batch, c->numPixels, need >> 20, totalB >> 20);
+        return PT_ENOMEM;
+    }
+    if (!c->batchAllocs.empty() && (!known || freeB < need + (size_t(1) << 30))) {
+        for (void* p : c->batchAllocs) (void)hipFree(p);
+        c->batchAllocs.clear();
+        c->batch = 0;
+        c->state = PathState{};
+        c->queues = Queues{};
+    }
+    PathState P{};
+    Queues Q{};
+    std::vector<void*> owned;
     P.numPixels = N;
     Q.numPixels = c->numPixels;
     Q.numBuckets = c->view.numBuckets;
     Q.numBlocks = (int)((N + kBlock - 1) / kBlock);
-    int rc;
-#define BA(ptr, count, zero) if ((rc = batchAlloc(c, &(ptr), (count), (zero))) != PT_OK) return rc
+    int rc = PT_OK;
+#define BA(ptr, count, zero) if (rc == PT_OK) rc = batchAlloc(owned, &(ptr), (count), (zero))
     BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
     BA(P.hitA, N * B, false); BA(P.hitB, N * B, false); BA(P.hitTri, N * B, false);
     BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.workQueue, N * B, false); BA(P.traceQueue, N * B, false);
@@ -192,7 +208,17 @@ int allocBatchState(PtContext* c, int batch)
     BA(Q.blockAlive, (size_t)Q.numBlocks * B, false);
     BA(Q.live, (size_t)(PT_MAX_DEPTH + 2) * B, true);
 #undef BA
+    if (rc != PT_OK) {
+        for (void* p : owned) (void)hipFree(p);
+        return rc;
+    }
+    for (void* p : c->batchAllocs) (void)hipFree(p);
+    c->batchAllocs = std::move(owned);
+    c->state = P;
+    c->queues = Q;
     c->batch = batch;
+    c->tuneStage = 0;           /* the launch shape is chosen for full groups of this size */
+    c->tuneChoice = 1;
     return PT_OK;
 }
 
@@ -917,6 +943,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
 
 static int traceBatch(PtContext* c, Batch bt)
 {
+    if (c->batch < 1 || bt.count < 1 || bt.count > c->batch) { pt_set_error("pt_trace: no path state for a group of %d iterations (allocated: %d)", bt.count, c->batch); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     SceneView V = c->view;
@@ -950,11 +977,13 @@ static int traceBatch(PtContext* c, Batch bt)
     bool tuning = false;
     if (!c->timing && meshes) {
         if (c->streamsFixed) groups = std::max(1, std::min(c->streamGroups, bt.count / c->rowsPerGroup));
-        else if (bt.count >= kTuneMinRows && count) { if (bt.count == c->tuneRows && c->tuneStage > kTuneShapes) shape = c->tuneChoice; }    /* counted kernels are no measure */
-        else if (bt.count >= kTuneMinRows) {
+        else if (bt.count >= kTuneMinRows && (count || bt.count != c->batch)) {
+            /* counted kernels are no measure, and only full groups (PT_OPT_BATCH iterations) take part in the
+             * choice: the remainder group of a range keeps the shape chosen so far and never restarts the trial */
+            if (c->tuneStage > kTuneShapes) shape = c->tuneChoice;
+        } else if (bt.count >= kTuneMinRows) {
             /* stages: 0 = a first group on one stream, unmeasured (first launches, no live-count hint yet);
-             * 1..kTuneShapes = measure that shape; then the choice stands until the group size changes */
-            if (bt.count != c->tuneRows) { c->tuneRows = bt.count; c->tuneStage = 0; }
+             * 1..kTuneShapes = measure that shape; then the choice stands until the group size is set anew */
             if (c->tuneStage == 0) shape = 1;
             else if (c->tuneStage <= kTuneShapes) { shape = c->tuneStage; tuning = true; }
             else shape = c->tuneChoice;
@@ -1029,7 +1058,7 @@ static int traceBatch(PtContext* c, Batch bt)
             if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] launch shape for groups of %d: %d (1-3 streams: %.2f / %.2f / %.2f ms, one stream with the shadow traversal in line: %.2f ms)\n", bt.count, c->tuneChoice, c->tuneMs[1], c->tuneMs[2], c->tuneMs[3], c->tuneMs[4]);
         }
     }
-    const bool tunePhase = !c->timing && meshes && !c->streamsFixed && !count && bt.count >= kTuneMinRows && c->tuneStage <= kTuneShapes;
+    const bool tunePhase = !c->timing && meshes && !c->streamsFixed && !count && bt.count >= kTuneMinRows && bt.count == c->batch && c->tuneStage <= kTuneShapes;
     if (tunePhase) c->tuneStage++;
     if (!c->hintPending) {
         HIP_TRY(hipMemcpyAsync(c->liveHintHost, (const char*)c->dc + offsetof(DevCounters, liveMax), sizeof(c->liveHint), hipMemcpyDeviceToHost, s));
@@ -1054,6 +1083,7 @@ int pt_trace_range(PtContext* c, int iter_begin, int iter_end, int iter_stride)
 {
     if (!c || iter_stride <= 0) { pt_set_error("pt_trace_range: bad argument"); return PT_EINVAL; }
     /* iterations are independent given their index: up to `batch` of them share every launch */
+    if (c->batch < 1) { pt_set_error("pt_trace_range: no path state is allocated"); return PT_EINVAL; }
     for (int it = iter_begin; it < iter_end;) {
         int remaining = (iter_end - it + iter_stride - 1) / iter_stride;
         Batch bt; bt.count = std::min(remaining, c->batch); bt.iterBase = it; bt.iterStride = iter_stride;
@@ -1169,6 +1199,7 @@ int pt_stats(PtContext* c, PtStats* out)
     out->launchesTrace = c->launches[ST_TRACE]; out->launchesShadowTrace = c->launches[ST_SHADOW_TRACE];
     out->tracedRays = h.workItems[0]; out->shadowRays = h.workItems[1];
     out->boxesTested = h.trav[0][3] + h.trav[1][3]; out->shadeBoxesTested = h.trav[1][3];
+    out->maxStackDepth = std::max(h.maxStack[0], h.maxStack[1]); out->ldsStackEntries = kLdsStack;
     return PT_OK;
 }
 
@@ -1262,6 +1293,7 @@ int pt_intersect_rays_noalloc(PtContext* c, const float* origins, const float* d
 int pt_capture_gbuffer(PtContext* c, int iter, float* normals, float* albedo)
 {
     if (!c) { pt_set_error("pt_capture_gbuffer: null context"); return PT_EINVAL; }
+    if (c->batch < 1) { pt_set_error("pt_capture_gbuffer: no path state is allocated"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)c->numPixels;
     if (!c->gNormals) { int rc = devAlloc(c, &c->gNormals, n * 3); if (rc != PT_OK) return rc; }
@@ -1315,6 +1347,7 @@ int pt_denoise(PtContext* c, float samples, int levels, float sigma_color, float
 int pt_camera_rays(PtContext* c, int iter, float* origins, float* directions)
 {
     if (!c || !origins || !directions) { pt_set_error("pt_camera_rays: null argument"); return PT_EINVAL; }
+    if (c->batch < 1) { pt_set_error("pt_camera_rays: no path state is allocated"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     const int n = c->numPixels;
     float *dO = nullptr, *dD = nullptr;

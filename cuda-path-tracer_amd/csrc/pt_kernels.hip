@@ -65,6 +65,7 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
     unsigned n = c.nodes, t = c.tris, h = c.meshHits, b = c.boxes;
     atomicMax(&dc->maxNodes[stage], n);
     atomicMax(&dc->maxTris[stage], t);
+    atomicMax(&dc->maxStack[stage], c.maxSp);
     for (int off = 32; off > 0; off >>= 1) {
         n += __shfl_down(n, off);
         t += __shfl_down(t, off);
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     int shLight = -1;           /* shadow mode: geom of the light, -1 for an environment ray */
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
 
     /* every wave leaves this loop: a lane's walk ends when its stack is empty, a wave stops fetching once all
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
     int vb = (int)blockIdx.x;
     if ((uint32_t)(vb * kBlock) >= n) return;
     const int numBuckets = S.numBuckets;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     do {
         const int slot = vb * kBlock + tid;
         if (sortOn) {
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     /* sorted order: the misses are the last bucket, and its first slot is the scanned histogram entry of that bucket's
      * first workgroup — their hit records (distance -1, nothing else read) are not fetched */
     const uint32_t missStart = sortOn ? (uint32_t)q.blockHist[(size_t)(S.numBuckets - 1) * q.numBlocks] : 0xffffffffu;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     do {
         const int slot = vb * kBlock + tid;
         const bool active = (uint32_t)slot < n;

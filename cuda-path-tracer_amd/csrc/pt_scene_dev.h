@@ -154,12 +154,13 @@ struct DevCounters {
     unsigned long long trav[2][4];      /* [0] intersect stage, [1] shade stage: nodes, triangles, mesh hits, child boxes */
     unsigned long long workItems[2];    /* rays handed to the traversal kernel: closest-hit, shadow */
     unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
+    unsigned maxStack[2];               /* deepest traversal stack any ray reached, per stage (entries; beyond kLdsStack they live in private memory) */
     unsigned long long waveDiag[2][6];  /* per traversal mode: wave iterations, node-step lanes, leaf-step lanes, held-leaf lanes, refills, refilled lanes */
     uint32_t lastLive[PT_MAX_DEPTH + 2];
     uint32_t liveMax[PT_MAX_DEPTH + 2]; /* per bounce, the largest live count over the rows of the last launch group */
 };
 
-struct TravCounters { uint32_t nodes, tris, meshHits, boxes; };
+struct TravCounters { uint32_t nodes, tris, meshHits, boxes, maxSp; };
 
 constexpr float kPI = 3.1415926535897932384626422832795028841971f;
 constexpr float kTWO_PI = 6.2831853071795864769252867665590057683943f;
@@ -389,6 +390,7 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         PT_PUSH(3) PT_PUSH(2) PT_PUSH(1)
 #undef PT_PUSH
         tv.sp = sp;
+        if (COUNT && (uint32_t)sp > cnt.maxSp) cnt.maxSp = (uint32_t)sp;
         if (tk[0] < INF) { tv.ref = rk[0]; return true; }
     } else {
         if (!leafTurn) return true;     /* hold the leaf until enough lanes of the wave have one */

@@ -195,6 +195,8 @@ typedef struct PtStats {
     uint64_t shadowRays;         /* shadow rays handed to the traversal (always)       */
     uint64_t boxesTested;        /* child boxes slab-tested, both modes (counters on)  */
     uint64_t shadeBoxesTested;   /* the shadow mode's share                            */
+    uint32_t maxStackDepth;      /* deepest traversal stack any ray reached (counters on) */
+    uint32_t ldsStackEntries;    /* entries per ray held in LDS; deeper ones spill to private memory */
 } PtStats;
 
 /* Closest-hit record for the fixed-ray-set parity hook. */

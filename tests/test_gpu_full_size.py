@@ -1,0 +1,270 @@
+"""GPU parity at the sizes the benchmark times, on real scanned geometry, and on the arms and corner cases the small
+scenes do not reach.
+
+  * closest hit, bit-exact vs the oracle, on the full-size dragon- (135 200), chess- (1.5 M) and halo-class (3.0 M
+    triangle) meshes: seeded rays from a sphere and rays leaving the third hit of a diffuse chain; the traversal's
+    stack must be seen to outgrow its LDS part, so the spill path is exercised; one whole iteration on each;
+  * the reference's own asset (tests/golden/Duck.glb) through the glTF import: closest hit and whole iterations;
+    where the prebuilt oracle/_ref/ref_tool travelled, the GPU is also compared with the reference's own
+    intersection code directly;
+  * sphere area light, emissive-texture termination;
+  * near-coincident surfaces (copies offset by a few ulps, coplanar faces) — the traversal visits leaves in another
+    order than the reference, which must not change the triangle chosen;
+  * radiance vs the oracle in libm arithmetic on the shading arms that use sin / cos / acos / atan2 / exp / log;
+  * an allocation failure leaves the context usable.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ref_binding as ref
+from test_gpu_parity import RMSE_TOL, _assert_full_parity, _hits_equal, _ray_set, _render_pair, _same_bits
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DUCK = os.path.join(HERE, "golden", "Duck.glb")
+
+
+def _cosine_about(normals, rng):
+    n = normals / np.maximum(np.linalg.norm(normals, axis=1, keepdims=True), 1e-20)
+    u1, u2 = rng.random(len(n), dtype=np.float32), rng.random(len(n), dtype=np.float32)
+    r, phi = np.sqrt(u1), 2 * np.pi * u2
+    a = np.where(np.abs(n[:, :1]) < 0.577, np.array([[1.0, 0, 0]], np.float32), np.array([[0, 1.0, 0]], np.float32))
+    t = np.cross(n, a)
+    t /= np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
+    b = np.cross(n, t)
+    d = t * (r * np.cos(phi))[:, None] + b * (r * np.sin(phi))[:, None] + n * np.sqrt(np.maximum(0.0, 1.0 - u1))[:, None]
+    return d.astype(np.float32)
+
+
+def _bounce3_rays(tr, n, seed):
+    """rays leaving the third hit of a chain of cosine-weighted bounces that starts at the camera (the GPU only
+    produces the INPUT here; what is checked is the closest hit of the final set)"""
+    rng = np.random.default_rng(seed)
+    o, d = tr.camera_rays(1)
+    sel = rng.integers(0, len(o), n)
+    o, d = o[sel], d[sel]
+    for _ in range(3):
+        h = tr.intersect(o, d)
+        idx = np.flatnonzero(h["t"] > 0)
+        sel = idx[rng.integers(0, len(idx), n)]
+        nrm = h["normal"][sel]
+        o = (o[sel] + d[sel] * h["t"][sel, None] + nrm * 1e-3).astype(np.float32)
+        d = _cosine_about(nrm, rng)
+    return o, d
+
+
+def _ref_check(sc, ro, rd, gpu_hits):
+    """the GPU against the reference's own boxIntersectionTest / sphereIntersectionTest / meshIntersectionTestBVH"""
+    if not ref.available():
+        return False
+    r = ref.intersect(sc, ro, rd)
+    assert np.array_equal(gpu_hits["geom"], r["geom"]) and gpu_hits["t"].tobytes() == r["t"].tobytes()
+    hit = r["t"] > 0
+    assert np.array_equal(gpu_hits["materialId"][hit], r["materialId"][hit])
+    assert gpu_hits["normal"][hit].tobytes() == r["normal"][hit].tobytes() and gpu_hits["uv"][hit].tobytes() == r["uv"][hit].tobytes()
+    return True
+
+
+@pytest.mark.parametrize("name,res,depth,nrays", [("dragon", (128, 128), 8, 100000), ("chess", (128, 72), 10, 100000),
+                                                  ("halo", (96, 96), 8, 100000)])
+def test_full_size_mesh_bit_exact(pt, scenes, orc, gpu_ok, name, res, depth, nrays):
+    sc = scenes.make_scene(name, res=res, depth=depth, tex_size=64, env_size=(256, 128))
+    ntri = int(sc.desc.contents.meshes[0].triangleCount)
+    assert ntri == {"dragon": 135200, "chess": 1499912, "halo": 3001250}[name]
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    ro, rd = _ray_set(31, nrays, center=(0.0, 5.0, 0.0), radius=14.0)
+    bo, bd = _bounce3_rays(tr, nrays, 7)
+    ro, rd = np.concatenate([ro, bo]), np.concatenate([rd, bd])
+    tr.set_option(pt.PT_OPT_COUNTERS, 1)
+    tr.reset_stats()
+    g = tr.intersect(ro, rd)
+    st = tr.stats()
+    tr.set_option(pt.PT_OPT_COUNTERS, 0)
+    assert _same_bits(tr.intersect(ro, rd)["t"], g["t"])            # counted and plain kernels agree
+    _hits_equal(g, o.intersect(ro, rd))
+    assert (g["triangle"] >= 0).sum() > nrays // 2
+    print("%s: %d triangles, deepest stack %d entries (%d in LDS), %.1f boxes / %.1f triangles per ray" % (
+        name, ntri, st.maxStackDepth, st.ldsStackEntries, st.boxesTested / len(ro), st.trisTested / len(ro)))
+    assert st.maxStackDepth > st.ldsStackEntries, "no ray reached the spill part of the traversal stack"
+    if name == "dragon":
+        assert _ref_check(sc, ro[:40000], rd[:40000], g[:40000]) or not ref.available()
+    # one whole iteration (closest-hit and shadow traversals, sort, shading, compaction) on the full-size tree
+    _assert_full_parity(pt, orc, sc, [1])
+
+
+def _duck_scene(pt, scenes, tmp_path, res):
+    d = scenes.scene_dict("duck")
+    d["Objects"][0]["FILE"] = DUCK
+    d["Objects"].append(dict(TYPE="cube", MATERIAL="light", TRANS=[0, 10, 0], ROTAT=[0, 0, 0], SCALE=[3, 0.3, 3]))
+    d["Camera"]["RES"] = list(res)
+    d["Camera"]["EYE"] = [0.0, 2.5, 9.0]
+    d["Camera"]["LOOKAT"] = [0.0, 2.0, 0.0]
+    p = tmp_path / "duck_real.json"
+    p.write_text(json.dumps(d))
+    sc = pt.Scene(p)
+    sc.set_envmap(scenes.sky_hdr(128, 64), 1.0)
+    return sc
+
+
+def test_reference_duck_asset_bit_exact(pt, scenes, orc, gpu_ok, tmp_path):
+    """gltf/Duck.glb of the reference (4 212 triangles, one textured PBR material, a node hierarchy with a matrix) as
+    scenes/duck.json places it, plus a cube light and a small sky."""
+    sc = _duck_scene(pt, scenes, tmp_path, (96, 96))
+    assert int(sc.desc.contents.meshes[0].triangleCount) == 4212 and len(sc.textures()) == 1
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    ro, rd = _ray_set(5, 60000, center=(0.0, 2.0, 0.0), radius=10.0)
+    g = tr.intersect(ro, rd)
+    _hits_equal(g, o.intersect(ro, rd))
+    assert (g["triangle"] >= 0).sum() > 3000
+    _ref_check(sc, ro, rd, g)
+    _assert_full_parity(pt, orc, sc, [1, 2, 3])
+
+
+def test_sphere_light_and_emissive_texture_bit_exact(pt, scenes, orc, gpu_ok, tmp_path):
+    """Area-light sampling on a sphere (sampleSphere, src/pathtrace.cu:1091-1110) from the diffuse and the PBR shader,
+    and a mesh whose material carries an emissive texture: texels with a non-zero colour end the path with
+    texel x emissiveFactor, black texels fall through to the material (src/pathtrace.cu:2530-2542)."""
+    d = scenes.scene_dict("cornell_orig")
+    d["Materials"]["polished_gold"] = dict(scenes.MATERIALS["polished_gold"])
+    d["Materials"]["plastic_red"] = dict(scenes.MATERIALS["plastic_red"])
+    d["Objects"][0] = scenes._obj("sphere", "light", (0, 8.5, 0), (0, 0, 0), (2.5, 2.5, 2.5))
+    d["Objects"] += [scenes._obj("sphere", "polished_gold", (2.5, 2, 1), (0, 0, 0), (3, 3, 3)),
+                     scenes._obj("sphere", "plastic_red", (-2.5, 2, 1), (0, 0, 0), (3, 3, 3)),
+                     scenes._obj("sphere", "light", (0, 1.0, 3), (0, 0, 0), (1.0, 1.0, 1.0))]       # a second, small sphere light
+    p = tmp_path / "sphere_light.json"
+    p.write_text(json.dumps(d))
+    sc = pt.Scene(p)
+    sc.set_resolution(96, 96)
+    rng = np.random.RandomState(3)
+    tex = np.zeros((16, 16, 3), np.uint8)
+    tex[4:12, 4:12] = rng.randint(60, 255, (8, 8, 3))             # glowing patch, black border
+    ti = sc.add_texture(tex)
+    glow = sc.add_material(type=pt.PT_PBR, color=[0.6, 0.6, 0.6], roughness=0.5, metallic=0.0, indexOfRefraction=1.5,
+                           emissiveTextureIdx=ti, emissiveFactor=[2.0, 1.5, 1.0])
+    ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    sc.add_mesh(scenes.blob_mesh(24, 25, 4, ident, [glow], radius=1.6, center=(0.0, 4.5, -1.5)))
+    tr, o = _assert_full_parity(pt, orc, sc, [1, 2, 3, 4])
+    # both outcomes of the emissive lookup occurred: some first hits on the mesh ended at once, others went on
+    og, od = tr.camera_rays(1)
+    h = tr.intersect(og, od)
+    on_mesh = int((h["triangle"] >= 0).sum())
+    assert on_mesh > 50
+    sc.set_depth(1)
+    tr1 = pt.Tracer(sc)
+    tr1.trace(1)
+    img = tr1.image().reshape(-1, 3)
+    lit = (img[h["triangle"] >= 0].sum(1) > 0).sum()
+    assert 0 < lit < on_mesh
+
+
+def _ulp_shift(a, rng, k=3):
+    """every float moved by -k..k units in the last place of its magnitude (sign kept, zero stays zero or becomes a
+    denormal, nothing becomes non-finite)"""
+    i = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    sign, mag = i & np.uint32(0x80000000), (i & np.uint32(0x7fffffff)).astype(np.int64)
+    mag = np.clip(mag + rng.randint(-k, k + 1, i.shape), 0, 0x7f7fffff).astype(np.uint32)
+    out = (sign | mag).view(np.float32)
+    assert np.isfinite(out).all()
+    return out
+
+
+def test_near_coincident_surfaces_bit_exact(pt, scenes, orc, gpu_ok):
+    """Two copies of a mesh a few ulps apart inside ONE BVH (near-equal distances in different leaves), the same as
+    separate geoms, and cubes that share a face plane with each other and with a flat blob face: the reference prunes
+    a leaf by its box's entry distance and keeps the first-visited triangle among exact ties; a traversal that
+    visits leaves in another order must still return the reference's triangle."""
+    sc = scenes.make_scene("cornell_orig", res=(64, 64), depth=8)
+    ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    m0 = sc.add_material(type=pt.PT_PBR, color=[0.9, 0.6, 0.3], roughness=0.4, metallic=0.0, indexOfRefraction=1.5)
+    m1 = sc.add_material(type=pt.PT_PBR, color=[0.3, 0.6, 0.9], roughness=0.2, metallic=1.0, indexOfRefraction=1.5)
+    rng = np.random.RandomState(17)
+    a = scenes.blob_mesh(48, 49, 21, ident, [m0], radius=1.8, center=(-1.5, 4.0, 0.0))
+    b = a.copy()
+    for f in ("v0", "v1", "v2"):
+        b[f] = _ulp_shift(a[f], rng)
+    b["materialId"] = m1
+    sc.add_mesh(np.concatenate([a, b]))                                # both copies under one tree
+    c = scenes.blob_mesh(40, 41, 22, ident, [m0], radius=1.5, center=(2.0, 4.0, 0.5))
+    c2 = c.copy()
+    for f in ("v0", "v1", "v2"):
+        c2[f] = _ulp_shift(c[f], rng, k=1)
+    c2["materialId"] = m1
+    sc.add_mesh(c)                                                      # the copies as two geoms
+    sc.add_mesh(c2)
+    sc.add_mesh(np.concatenate([scenes.cube_mesh(((0.0, 7.5, 0.0), (0.0, 0.0, 0.0), (2.0, 1.0, 2.0)), m0),
+                                scenes.cube_mesh(((1.0, 7.5, 0.0), (0.0, 0.0, 0.0), (2.0, 1.0, 2.0)), m1),      # overlapping, coplanar faces
+                                scenes.cube_mesh(((0.0, 8.5, 0.0), (0.0, 0.0, 0.0), (2.0, 1.0, 2.0)), m1)]))    # stacked: shared face plane
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    ro, rd = _ray_set(41, 120000, center=(0.0, 5.0, 0.0), radius=9.0)
+    # axis-parallel rays along the shared planes' normals and grazing along them
+    xs = np.linspace(-1.4, 2.4, 60, dtype=np.float32)
+    gx, gz = np.meshgrid(xs, xs)
+    down_o = np.stack([gx.ravel(), np.full(gx.size, 9.5, np.float32), gz.ravel()], 1).astype(np.float32)
+    down_d = np.tile(np.array([[0, -1, 0]], np.float32), (gx.size, 1))
+    side_o = np.stack([np.full(gx.size, -8.0, np.float32), 7.0 + (gx.ravel() + 1.4) / 3.8 * 2.0, gz.ravel()], 1).astype(np.float32)
+    side_d = np.tile(np.array([[1, 0, 0]], np.float32), (gx.size, 1))
+    ro, rd = np.concatenate([ro, down_o, side_o]), np.concatenate([rd, down_d, side_d])
+    g = tr.intersect(ro, rd)
+    ob = o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    mesh_hits = g[g["triangle"] >= 0]
+    assert len(mesh_hits) > 8000 and len(set(mesh_hits["geom"].tolist())) == 4
+    # both copies of the doubled mesh win somewhere: the near-ties are real
+    first = mesh_hits[mesh_hits["geom"] == min(mesh_hits["geom"])]
+    assert 0 < (first["materialId"] == m0).sum() < len(first)
+    _ref_check(sc, ro, rd, g)
+    _assert_full_parity(pt, orc, sc, [1, 2])
+
+
+@pytest.mark.parametrize("name,kw", [("sss", dict(res=(96, 96), depth=8)), ("pbr", dict(res=(96, 96), depth=8, env=True, env_size=(256, 128))),
+                                     ("dragon", dict(res=(96, 96), depth=8, grid=(64, 65), env_size=(128, 64), tex_size=32)),
+                                     ("chess", dict(res=(96, 96), depth=10, grid=(48, 49), env_size=(128, 64), tex_size=32))])
+def test_radiance_rmse_vs_reference_arithmetic_all_arms(pt, scenes, orc, gpu_ok, name, kw):
+    """GPU (fixed-sequence sin / cos / acos / atan2 / exp / log / pow) vs the oracle with glibc's functions — the arithmetic
+    a host build of the reference performs — on the arms that use them: dipole subsurface profile (exp / log), GGX
+    and Fresnel (pow), environment lookups and importance sampling (acos / atan2 / sin), light sampling (sin / cos /
+    acos).  Paths whose branch decisions flip diverge, so the bar is statistical: per-channel RMSE of the 16-sample
+    mean image <= RMSE_TOL of the mean radiance, and equal image means within half a percent."""
+    sc = scenes.make_scene(name, **kw)
+    spp = 16
+    tr, o, _ = _render_pair(pt, orc, sc, range(1, spp + 1), orc.MATH_LIBM)
+    gi, oi = tr.image() / spp, o.image() / spp
+    mean = oi.reshape(-1, 3).mean(0)
+    rmse = np.sqrt(((gi - oi) ** 2).reshape(-1, 3).mean(0))
+    print(name, "rmse / mean", rmse / mean, "path-bounces", tr.stats().pathBounces, o.stats().pathBounces)
+    assert np.all(rmse / mean <= RMSE_TOL), (rmse / mean)
+    assert np.allclose(gi.reshape(-1, 3).mean(0), mean, rtol=5e-3)
+    assert abs(int(tr.stats().pathBounces) - int(o.stats().pathBounces)) <= 2e-3 * o.stats().pathBounces
+
+
+def test_allocation_failure_leaves_context_usable(pt, scenes, orc, gpu_ok):
+    """PT_OPT_BATCH beyond what the device can hold fails with PT_ENOMEM; the context keeps its path state and renders
+    the same picture afterwards, through pt_trace and pt_trace_range."""
+    sc = scenes.make_scene("dragon", res=(4096, 4096), depth=4, grid=(24, 25), env_size=(64, 32), tex_size=16)
+    os.environ["PT_BATCH"] = "1"
+    try:
+        tr = pt.Tracer(sc)
+    finally:
+        del os.environ["PT_BATCH"]
+    tr.trace(1)
+    before = tr.image().copy()
+    with pytest.raises(pt.PtError, match="needs about"):
+        tr.set_option(pt.PT_OPT_BATCH, 512)             # 4096^2 x 512 x 190 B = 1.6 TB
+    tr.clear()
+    tr.trace(1)
+    assert _same_bits(tr.image(), before)
+    tr.clear()
+    tr.trace_range(1, 2)
+    assert _same_bits(tr.image(), before)
+    hits = tr.intersect(*_ray_set(2, 1000))
+    assert len(hits) == 1000
+    tr.set_option(pt.PT_OPT_BATCH, 2)                   # and a size that fits is still accepted
+    tr.clear()
+    tr.trace_range(1, 3)
+    tr.sync()
