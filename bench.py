@@ -5,19 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one launch group of the wavefront loop on every rank: --spp-per-step iterations (one sample per
-pixel each, default 128) that share every kernel launch.  Ranks render disjoint, interleaved iteration
-indices of the same replicated scene (iterations are independent given the iteration index, which seeds
-every RNG stream); after the timed steps the per-rank running sums are summed with one all-reduce over
-RCCL.  value = path-bounces of all ranks / time (path-bounce = one live
-path entering the intersect stage for one bounce).
+pixel each) that share every kernel launch.  Ranks render disjoint, interleaved iteration indices of the same
+replicated scene (iterations are independent given the iteration index, which seeds every RNG stream); after the
+timed steps the per-rank running sums are summed with one all-reduce over RCCL.  value = path-bounces of all
+ranks / time (path-bounce = one live path entering the intersect stage for one bounce).
+
+--scaling weak (default): every rank renders --spp-per-step iterations per step, whatever the number of ranks.
+--scaling strong --total-spp S: a step is S samples per pixel in total, S / ranks on every rank.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,20 +31,99 @@ WORKLOADS = {
     # name: (scene, resolution, depth, description)
     "dragon": ("dragon", (1920, 1080), 8,
                "dragon.json @1920x1080 depth 8 (procedural stand-in for the undistributed DragonAttenuation.glb: "
-               "135200-triangle closed mesh, 6 PBR materials incl. one transmissive, cube light, "
+               "135200-triangle mesh, 6 PBR materials incl. one transmissive, cube light, "
                "2048x1024 procedural HDR env, intensity 0.6)"),
     "cornell": ("cornell", (800, 800), 8, "cornell.json @800x800 depth 8, env map absent (9 primitives, 13 materials)"),
     "chess": ("chess", (1920, 1080), 10, "chess.json @1920x1080 depth 10 (stand-in: 1.5M triangles, 18 textured PBR materials, HDR env)"),
     "sss": ("sss", (1920, 1080), 8, "sss.json @1920x1080 depth 8"),
     "sss32": ("sss", (1920, 1080), 32, "sss.json @1920x1080 depth 32"),
     "halo": ("halo", (3840, 2160), 8, "halo.json @3840x2160 depth 8 (stand-in: 3.0M triangles, 13 materials, two lights, HDR env)"),
+    "p911": ("p911", (3840, 2160), 8, "911.json @3840x2160 depth 8 (stand-in: 3.0M triangles, 16 textured materials, light of emittance 1, HDR env intensity 3)"),
+    "duck": ("duck_real", (1920, 1080), 8, "duck.json @1920x1080 depth 8: the reference's own gltf/Duck.glb (4212 triangles, one textured PBR "
+                                            "material) through the glTF import, procedural HDR env in place of the undistributed one"),
 }
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
-
-
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+CLOCK_GHZ = 2.4
+# fp32 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s (x 2 flop for an FMA, x 2 again
+# for packed / dual-issue forms = the 157.3 TFLOP/s headline figure)
+VALU_LANE_PEAK_GINST = 256 * 4 * 16 * CLOCK_GHZ
+VALU_PEAK_TFLOPS = 157.3
 TUNE_GROUPS = 5      # launch groups the library uses to pick its launch shape (one unmeasured, then 1 / 2 / 3 streams and one stream alone)
+
+
+def iteration_range(rank, world, per_rank_per_step, step_begin, step_end):
+    """(begin, end, stride) of pt_trace_range for the steps [step_begin, step_end) of one rank: rank r of R renders
+    the iteration indices 1 + r, 1 + r + R, ...; a step is per_rank_per_step of them on every rank."""
+    return (1 + rank + step_begin * per_rank_per_step * world, 1 + rank + step_end * per_rank_per_step * world, world)
+
+
+def per_rank_iterations(scaling, world, spp_per_step, total_spp):
+    """iterations one rank renders per step.  strong: total_spp samples per pixel are split evenly over the ranks.  The
+    union of the ranks' iteration indices is 1 .. total_spp exactly as one GPU would render them, so the four
+    jitter cells (iteration % 4) stay balanced when total_spp is a multiple of 4 — a single rank sees only some of the
+    cells once the stride is even, which does not matter for the sum."""
+    if scaling == "weak":
+        return spp_per_step
+    block = 4 * world // math.gcd(4, world)            # lcm(4, ranks)
+    if total_spp <= 0 or total_spp % block:
+        raise SystemExit("--total-spp must be a positive multiple of %d for %d ranks" % (block, world))
+    return total_spp // world
+
+
+def scene_directory(rank):
+    """every rank writes its scene file into a directory of its own (ranks start at the same time)"""
+    return os.path.join(tempfile.gettempdir(), "mi_pathtrace_bench_%d_rank%d" % (os.getuid(), rank))
+
+
+def make_workload_scene(scenes, pt, name, res, depth, rank):
+    if name == "duck_real":
+        return scenes.make_duck_scene(res=res, depth=depth, directory=scene_directory(rank))
+    return scenes.make_scene(name, res=res, depth=depth, directory=scene_directory(rank))
+
+
+def _ray_sets(pt, tr, npix):
+    """closest-hit stage alone on two fixed sets of one image's worth of rays (production kernels through the
+    fixed-ray-set hook, device time of the traversal kernel): the primary rays of iteration 1, and rays leaving the
+    third hit of a chain of cosine-weighted bounces that starts with them"""
+    import numpy as np
+    rng = np.random.default_rng(12345)
+
+    def cosine_about(n):
+        n = n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+        u1, u2 = rng.random(len(n), dtype=np.float32), rng.random(len(n), dtype=np.float32)
+        r, phi = np.sqrt(u1), 2 * np.pi * u2
+        a = np.where(np.abs(n[:, :1]) < 0.577, np.array([[1.0, 0, 0]], np.float32), np.array([[0, 1.0, 0]], np.float32))
+        t = np.cross(n, a)
+        t /= np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
+        b = np.cross(n, t)
+        return (t * (r * np.cos(phi))[:, None] + b * (r * np.sin(phi))[:, None] + n * np.sqrt(np.maximum(0.0, 1.0 - u1))[:, None]).astype(np.float32)
+
+    def timed(o, d):
+        tr.intersect(o, d)
+        tr.set_option(pt.PT_OPT_STAGE_TIMING, 1)
+        tr.reset_stats()
+        h = tr.intersect(o, d)
+        st = tr.stats()
+        tr.set_option(pt.PT_OPT_STAGE_TIMING, 0)
+        ms = st.msTrace + st.msIntersect
+        return h, (round(len(o) / ms / 1e3, 1) if ms > 0 else None), (round(len(o) / st.msTrace / 1e3, 1) if st.msTrace > 0 else None)
+
+    o, d = tr.camera_rays(1)
+    h, primary_stage, primary_trav = timed(o, d)
+    out = {"rays_per_set": int(npix), "primary_Mrays_s": primary_stage, "primary_traversal_Mrays_s": primary_trav}
+    if not (h["t"] > 0).any():
+        return out
+    for bounce in range(3):
+        idx = np.flatnonzero(h["t"] > 0)
+        sel = idx[rng.integers(0, len(idx), npix)]
+        nrm = h["normal"][sel]
+        o, d = (o[sel] + d[sel] * h["t"][sel, None] + nrm * 1e-3).astype(np.float32), cosine_about(nrm)
+        if bounce < 2:
+            h = tr.intersect(o, d)
+    _h, stage, trav = timed(o, d)
+    out.update({"bounce3_Mrays_s": stage, "bounce3_traversal_Mrays_s": trav})
+    return out
 
 
 def main():
@@ -51,8 +134,11 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=0,
                     help="iterations sharing one launch group = one step (1..512); 0 = the largest power of two whose path state "
                          "stays below 210 GB (512 at 1920x1080, 128 at 3840x2160)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--total-spp", type=int, default=512, help="--scaling strong: samples per pixel of one step, split over the ranks")
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-iteration and ray-set measurements after the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo only to rehearse several ranks on a box with fewer GPUs")
     ap.add_argument("--no-sort", action="store_true", help="MATERIAL_SORTING 0")
@@ -84,7 +170,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     scene_name, res, depth, desc = WORKLOADS[args.workload]
-    sc = scenes.make_scene(scene_name, res=res, depth=depth)
+    sc = make_workload_scene(scenes, pt, scene_name, res, depth, rank)
     tr = pt.Tracer(sc, device=local_rank)
     if args.no_sort:
         tr.set_option(pt.PT_OPT_MATERIAL_SORT, 0)
@@ -103,13 +189,13 @@ def main():
     # and not per iteration, so groups are as large as 210 GB of path state (about 190 B per pixel and iteration) allow,
     # in powers of two so that the persistent traversal grid divides evenly over the rows
     budget = min(210e9, 0.8 * torch.cuda.mem_get_info()[0])       # never more than four fifths of what is free now
+    per_step = per_rank_iterations(args.scaling, world, args.spp_per_step, args.total_spp)
     B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 190.0 * b <= budget)
+    if args.scaling == "strong":
+        B = min(B, per_step)
     B = max(1, min(B, 512))
 
-    def it_index(step):          # interleaved sample split: rank r renders 1+r, 1+r+R, ...; B of them per step
-        return 1 + rank + step * B * world
-
-    # ---- untimed: context set-up (the library tries its launch shapes on the first five launch groups of a size and
+    # ---- untimed: context set-up (the library tries its launch shapes on the first five full launch groups and
     # keeps the fastest), warmup, then a counted pass over the timed iterations (exact node / triangle counts)
     while True:
         try:
@@ -119,27 +205,32 @@ def main():
             if args.spp_per_step > 0 or B <= 8:
                 raise
             B //= 2                                   # a GPU with less free memory than planned for: smaller groups
-    if world > 1:                                     # every rank uses the same group size (it fixes the iteration indices)
+    if world > 1:                                     # every rank uses the same group size
         t = torch.tensor([B], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) != B:
             B = int(t.item())
             tr.set_option(pt.PT_OPT_BATCH, B)
-    tr.trace_range(it_index(0), it_index(TUNE_GROUPS), world)
+    if args.scaling == "weak":
+        per_step = B
+
+    def steps_range(a, b):
+        return iteration_range(rank, world, per_step, a, b)
+
+    tr.trace_range(*iteration_range(rank, world, B, 0, TUNE_GROUPS))
     barrier()
     tr.clear()
     if args.warmup:
-        tr.trace_range(it_index(0), it_index(args.warmup), world)
+        tr.trace_range(*steps_range(0, args.warmup))
     barrier()
     tr.reset_stats()
     tr.clear()
     tr.set_option(pt.PT_OPT_COUNTERS, 1)
-    count_steps = 1
-    tr.trace_range(it_index(args.warmup), it_index(args.warmup + count_steps), world)
+    tr.trace_range(*steps_range(args.warmup, args.warmup + 1))
     cs = tr.stats()
     counted = dict(pb=cs.pathBounces, rays=cs.tracedRays, shadow_rays=cs.shadowRays,
                    boxes=cs.boxesTested - cs.shadeBoxesTested, tris=cs.trisTested - cs.shadeTrisTested, hits=cs.meshHits - cs.shadeMeshHits,
-                   s_boxes=cs.shadeBoxesTested, s_tris=cs.shadeTrisTested)
+                   s_boxes=cs.shadeBoxesTested, s_tris=cs.shadeTrisTested, max_stack=cs.maxStackDepth)
     tr.set_option(pt.PT_OPT_COUNTERS, 0)
     tr.reset_stats()
     tr.clear()
@@ -147,7 +238,7 @@ def main():
     # ---- timed region: exactly K steps
     barrier()
     t0 = time.perf_counter()
-    tr.trace_range(it_index(args.warmup), it_index(args.warmup + args.steps), world)     # exactly K iterations per rank
+    tr.trace_range(*steps_range(args.warmup, args.warmup + args.steps))
     tr.sync()
     if world > 1:
         dist.all_reduce(image)                      # RCCL sum of the W*H*3 accumulation buffers
@@ -162,7 +253,7 @@ def main():
     tr.reset_stats()
     tr.set_option(pt.PT_OPT_STAGE_TIMING, 1)
     p0 = time.perf_counter()
-    tr.trace_range(it_index(args.warmup), it_index(args.warmup + args.steps), world)
+    tr.trace_range(*steps_range(args.warmup, args.warmup + args.steps))
     tr.sync()
     p1 = time.perf_counter()
     st = tr.stats()
@@ -171,62 +262,74 @@ def main():
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     pbs = torch.tensor([float(total_stats.pathBounces)], dtype=torch.float64, device="cuda")
     if world > 1:
+        if args.backend == "gloo":
+            elapsed, pbs = elapsed.cpu(), pbs.cpu()
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(pbs, op=dist.ReduceOp.SUM)
     elapsed = float(elapsed.item())
     total_pb = float(pbs.item())
+    spp_rank = args.steps * per_step               # iterations one rank rendered in the timed region
 
     out = None
     if rank == 0:
         value = total_pb / elapsed / 1e6
-        # ---- roofline of the dominant kernel (by accumulated HIP-event time): the BVH traversal kernel in
-        # closest-hit mode.  Algorithmic bytes per path-bounce of the whole loop = 192 streaming bytes
-        # (path state read + written 96, hit record written + read 56, sort key + index 16, image 24)
-        # + 32 B per child box tested + 36 B per triangle tested + 64 B of attributes per mesh hit.
-        # The traversal kernel's share, per ray it is handed: 4 B queue entry + 48 B path state read
-        # + 28 B hit record written, plus its own box / triangle / attribute bytes (exact counts from
-        # the counted pass over the first iterations of the timed range).
         stages = {"k_trace(closest)": st.msTrace, "k_trace(shadow)": st.msShadowTrace,
-                  "k_prims": st.msIntersect - st.msTrace,
+                  "k_prims": st.msIntersect - st.msTrace, "k_camera": st.msCamera,
                   "k_shade": st.msShade - st.msShadowTrace, "sort": st.msSort, "compact": st.msCompact}
-        per_ray = 1.0 / max(counted["rays"], 1)
-        boxes, tris, hits = counted["boxes"] * per_ray, counted["tris"] * per_ray, counted["hits"] * per_ray
-        b_ray = 80.0 + 32.0 * boxes + 36.0 * tris + 64.0 * hits
-        rays_per_launch = st.tracedRays / max(st.launchesTrace, 1)
-        avg_ms = st.msTrace / max(st.launchesTrace, 1)
-        achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # fp32 VALU view of the same kernel: 30 flop per box, 53 per triangle, 36 + 120 per ray (set-up, epilogue)
-        flops_ray = 30.0 * boxes + 53.0 * tris + 36.0 + 120.0 * hits
-        valu_tflops = (flops_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        b_loop = 192.0 + (32.0 * (counted["boxes"] + counted["s_boxes"]) + 36.0 * (counted["tris"] + counted["s_tris"])
-                          + 64.0 * counted["hits"]) / max(counted["pb"], 1)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        measured_in = ("a second pass over the same %d steps with HIP events around every stage and the launch group on one "
+                       "stream (%.3f ms per spp; the timed region runs each group on the one to three streams the library picked during set-up)"
+                       % (args.steps, (p1 - p0) / max(spp_rank, 1) * 1e3))
+        pmc = {}
+        ppath = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+        if os.path.exists(ppath):
             try:
-                traffic = json.load(open(tpath)).get("k_trace(closest)")
+                pmc = json.load(open(ppath))
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_gbs": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None),
-                    "note": "algorithmic bytes follow the per-unit definition (32 B per child box tested, 36 B per triangle, 64 B per mesh "
-                            "hit, 80 B of path state and hit record per ray); the BVH stays in L2 / Infinity Cache, so the HBM traffic the "
-                            "counters see (traffic, traffic_gbs) is far below it and the kernel is bound by dependent-fetch latency and "
-                            "SIMD lane divergence, not by HBM",
-                    "alg_bytes_per_ray": round(b_ray, 1), "rays_per_launch": round(rays_per_launch, 1),
-                    "avg_launch_ms": round(avg_ms, 5), "launches": st.launchesTrace,
-                    "boxes_per_ray": round(boxes, 2), "tris_per_ray": round(tris, 2), "mesh_hit_rate": round(hits, 3),
-                    "valu_fp32_tflops": round(valu_tflops, 2), "valu_fp32_peak_tflops": VALU_PEAK_TFLOPS,
-                    "valu_frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
-                    "loop_alg_bytes_per_path_bounce": round(b_loop, 1),
-                    "loop_alg_gbs": round(b_loop * total_pb / world / elapsed / 1e9, 1),
-                    "stage_ms_per_spp": {k: round(v / (args.steps * B), 4) for k, v in stages.items()},
-                    "measured_in": "a second pass over the same %d steps with HIP events around every stage and the launch group on one "
-                                   "stream (%.3f ms per spp; the timed region runs each group on the one to three streams the library picked during set-up)"
-                                   % (args.steps, (p1 - p0) / (args.steps * B) * 1e3)}
-
-        if st.launchesTrace == 0:
+                pmc = {}
+        if st.launchesTrace > 0:
+            # ---- roofline of the dominant kernel, the BVH traversal in closest-hit mode.
+            # Its data (nodes, triangles) are served by L2 / Infinity Cache, so HBM is not what bounds it: the binding
+            # resource is vector instruction issue under lane divergence.  achieved = fp32-lane instructions the kernel
+            # retires per second = VALU wave-instructions per launch x active lanes per instruction (hardware counters
+            # of a profiled run of this workload, profiles/pmc_<workload>.json) / this run's own launch duration (HIP
+            # events); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  frac is therefore issue utilisation x lane
+            # utilisation.  traffic = HBM bytes per launch from the same profile.
+            per_ray = 1.0 / max(counted["rays"], 1)
+            boxes, tris, hits = counted["boxes"] * per_ray, counted["tris"] * per_ray, counted["hits"] * per_ray
+            b_ray = 80.0 + 32.0 * boxes + 36.0 * tris + 64.0 * hits
+            rays_per_launch = st.tracedRays / max(st.launchesTrace, 1)
+            avg_ms = st.msTrace / max(st.launchesTrace, 1)
+            alg_gbs = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            flops_ray = 30.0 * boxes + 53.0 * tris + 36.0 + 120.0 * hits
+            valu_tflops = (flops_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            k = pmc.get("k_trace(closest)", {})
+            # the counters are per ray handed to the kernel, so that a run with another group size can use them
+            lane_inst_per_ray = k.get("valu_lane_instructions_per_ray")
+            traffic_per_ray = k.get("hbm_bytes_per_ray")
+            achieved = (lane_inst_per_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if (lane_inst_per_ray and avg_ms > 0) else None
+            traffic = round(traffic_per_ray * rays_per_launch) if traffic_per_ray else None
+            roofline = {"bound": "valu_issue", "kernel": "k_trace<closest>",
+                        "achieved": round(achieved, 1) if achieved else None, "peak": round(VALU_LANE_PEAK_GINST, 1),
+                        "unit": "G fp32-lane instructions/s",
+                        "frac": round(achieved / VALU_LANE_PEAK_GINST, 4) if achieved else None,
+                        "traffic": traffic,
+                        "traffic_gbs": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None),
+                        "hbm_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None),
+                        "issue_utilisation": k.get("valu_issue_utilisation"), "lane_utilisation": k.get("valu_lane_utilisation"),
+                        "l2_hit_rate": k.get("l2_hit_rate"),
+                        "counters_from": ("profiles/pmc_%s.json (rocprofv3 --pmc passes of this workload)" % args.workload) if k else None,
+                        "note": "the BVH is served by L2 / Infinity Cache: the kernel is bound by vector instruction issue under lane divergence "
+                                "(frac = issue utilisation x lane utilisation), not by HBM (hbm_frac = measured HBM traffic / 8 TB/s); "
+                                "alg_gbs is the algorithmic-byte rate (32 B per child box tested, 36 B per triangle, 64 B per mesh hit, 80 B of "
+                                "path state and hit record per ray), which the caches serve and which therefore is no fraction of HBM bandwidth",
+                        "alg_bytes_per_ray": round(b_ray, 1), "alg_gbs": round(alg_gbs, 1), "rays_per_launch": round(rays_per_launch, 1),
+                        "avg_launch_ms": round(avg_ms, 5), "launches": st.launchesTrace,
+                        "boxes_per_ray": round(boxes, 2), "tris_per_ray": round(tris, 2), "mesh_hit_rate": round(hits, 3),
+                        "deepest_stack": counted["max_stack"],
+                        "valu_fp32_tflops": round(valu_tflops, 2), "valu_fp32_peak_tflops": VALU_PEAK_TFLOPS,
+                        "stage_ms_per_spp": {k2: round(v / max(spp_rank, 1), 4) for k2, v in stages.items()},
+                        "measured_in": measured_in}
+        else:
             # analytic scenes (no BVH mesh): the streaming kernels are all there is; the larger of the two stages is reported
             # with its share of the 192 streaming bytes per path-bounce (intersect 84 = path read 48 + hit written 28 + key and
             # index 8; shade 108 = path written 48 + hit read 28 + key and index read 8 + image 24)
@@ -239,7 +342,30 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                         "alg_bytes_per_path_bounce": b_pb, "path_bounces_per_launch": round(units, 1),
                         "avg_launch_ms": round(avg_ms, 5), "launches": launches,
-                        "stage_ms_per_spp": roofline["stage_ms_per_spp"], "measured_in": roofline["measured_in"]}
+                        "stage_ms_per_spp": {k2: round(v / max(spp_rank, 1), 4) for k2, v in stages.items()}, "measured_in": measured_in}
+
+        live = [int(v) for v in st.lastLive[:depth + 1]]
+        extras = {}
+        if not args.no_extras and world == 1:
+            # ---- the reference-shaped call: one iteration per call of pathtrace(pbo = NULL, frame, iteration)
+            n_single = 48
+            tr.clear()
+            tr.trace(1)
+            tr.sync()
+            tr.reset_stats()
+            s0 = time.perf_counter()
+            for it in range(2, 2 + n_single):
+                tr.trace(it)
+            tr.sync()
+            s1 = time.perf_counter()
+            ss = tr.stats()
+            extras["single_iteration"] = {"ms_per_iter": round((s1 - s0) / n_single * 1e3, 4),
+                                          "Mpaths_bounce_s": round(ss.pathBounces / (s1 - s0) / 1e6, 1), "iterations": n_single,
+                                          "path_state_bytes_in_flight": int(176 * npix),
+                                          "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end"}
+            extras["path_state_bytes_in_flight"] = int(176 * npix) * B
+            if st.launchesTrace > 0:
+                extras["ray_sets"] = _ray_sets(pt, tr, npix)
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only
@@ -259,15 +385,22 @@ def main():
                              "OpenMP over queue slots, libm arithmetic" % (cpu_spp, os_.pathBounces, c1 - c0)}
             o.close()
 
-        out = {"metric": "Mpaths*bounce/s (%s)" % scene_name, "value": round(value, 3), "unit": "Mpaths*bounce/s",
+        pb_spp = st.pathBounces / max(spp_rank, 1)
+        out = {"metric": "Mpaths*bounce/s (%s)" % args.workload, "value": round(value, 3), "unit": "Mpaths*bounce/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": desc, "resolution": list(res), "depth": depth, "spp_per_step_per_gpu": B,
-                          "ms_per_spp": round(elapsed / (args.steps * B) * 1e3, 5),
+               "config": {"workload": desc, "resolution": list(res), "depth": depth, "spp_per_step_per_gpu": per_step,
+                          "iterations_per_launch_group": B,
+                          "ms_per_spp": round(elapsed / max(spp_rank * world, 1) * 1e3, 5),
                           "material_sort": not args.no_sort, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
-                          "path_bounces_per_spp": round(st.pathBounces / max(args.steps * B, 1), 1)},
+                          "path_bounces_per_spp": round(pb_spp, 1),
+                          "live_paths_per_bounce_last_iteration": live,
+                          "secondary_fraction_of_path_bounces": round(1.0 - npix / max(pb_spp, 1.0), 4),
+                          "traversal_rays_per_spp": round(st.tracedRays / max(spp_rank, 1), 1),
+                          "shadow_rays_per_spp": round(st.shadowRays / max(spp_rank, 1), 1)},
                "roofline": roofline, "cpu_baseline": cpu}
+        out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

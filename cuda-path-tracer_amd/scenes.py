@@ -149,8 +149,12 @@ def write_scene_json(name, directory=None):
     directory = directory or os.path.join(tempfile.gettempdir(), "mi_pathtrace_scenes_%d" % os.getuid())
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, name + ".json")
-    with open(path, "w") as f:
+    # written under a name of its own and renamed into place: several processes may prepare the same scene at once
+    # (ranks of a multi-GPU run that share a directory), and none of them may ever read a half-written file
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    with open(tmp, "w") as f:
         json.dump(scene_dict(name), f, indent=1)
+    os.replace(tmp, path)
     return path
 
 
@@ -211,6 +215,234 @@ def blob_mesh(n_lon, n_lat, seed, trs, material_ids, bumps=6, amplitude=0.18, ra
         t["materialId"] = mids[patch[sel]]
         out.append(t)
     return np.concatenate(out)
+
+
+def _grid_mesh(pos, nrm, uv, mat_of_quad, flip=False):
+    """(nu+1, nv+1) grids of positions / normals / uvs -> 2*nu*nv triangles (TRI_DTYPE); mat_of_quad: (nu, nv) ints."""
+    nu, nv = pos.shape[0] - 1, pos.shape[1] - 1
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    corners = ((i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1))
+    order = ((0, 1, 2), (0, 2, 3)) if not flip else ((0, 2, 1), (0, 3, 2))
+    out = np.zeros(2 * nu * nv, dtype=TRI_DTYPE)
+    for k, tri in enumerate(order):
+        t = out[k::2]
+        for (name_v, name_n, name_uv), c in zip((("v0", "n0", "uv0"), ("v1", "n1", "uv1"), ("v2", "n2", "uv2")), tri):
+            a, b = corners[c]
+            t[name_v] = pos[a, b]
+            t[name_n] = nrm[a, b] if not flip else -nrm[a, b]
+            t[name_uv] = uv[a, b]
+        t["materialId"] = mat_of_quad[i, j]
+    return out
+
+
+def _grid_normals(pos, wrap_u, wrap_v):
+    """unit normals of a parametric grid by central differences (periodic where the surface closes on itself)"""
+    def diff(a, axis, wrap):
+        if wrap:          # first and last sample coincide
+            core = np.take(a, range(a.shape[axis] - 1), axis=axis)
+            d = np.roll(core, -1, axis=axis) - np.roll(core, 1, axis=axis)
+            return np.concatenate([d, np.take(d, [0], axis=axis)], axis=axis)
+        return np.gradient(a, axis=axis)
+    n = np.cross(diff(pos, 0, wrap_u), diff(pos, 1, wrap_v))
+    ln = np.linalg.norm(n, axis=-1, keepdims=True)
+    return np.where(ln > 1e-20, n / np.maximum(ln, 1e-20), np.array([0.0, 1.0, 0.0]))
+
+
+def _patch_materials(nu, nv, mids, pu, pv, shift=0):
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    mids = np.asarray(mids, np.int32)
+    return mids[((i * pu // max(nu, 1)) * (pv + 1) + (j * pv // max(nv, 1)) + shift) % len(mids)]
+
+
+def _split(budget, aspect):
+    """(nu, nv) with 2 * nu * nv <= budget, nu / nv about aspect"""
+    nv = max(3, int(np.sqrt(budget / 2.0 / aspect)))
+    nu = max(3, int(budget // (2 * nv)))
+    return nu, nv
+
+
+def _knot_tube(budget, rng, mids, p=2, q=3, r0=0.13):
+    """closed tube around a (p, q) torus knot with a rippled radius: strongly concave, parts of it pass close to
+    other parts"""
+    nu, nv = _split(budget, 14.0)
+    u = np.linspace(0.0, 2.0 * np.pi, nu + 1)
+    v = np.linspace(0.0, 2.0 * np.pi, nv + 1)
+
+    def curve(t):
+        r = 0.62 + 0.26 * np.cos(q * t)
+        return np.stack([r * np.cos(p * t), 0.30 * np.sin(q * t), r * np.sin(p * t)], -1)
+    c = curve(u)
+    tan = curve(u + 1e-4) - curve(u - 1e-4)
+    tan /= np.linalg.norm(tan, axis=-1, keepdims=True)
+    side = np.cross(tan, np.array([0.0, 1.0, 0.0]))
+    side /= np.maximum(np.linalg.norm(side, axis=-1, keepdims=True), 1e-9)
+    up = np.cross(side, tan)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    a, b, ph = rng.randint(5, 12), rng.randint(3, 7), rng.uniform(0, 6.28)
+    rad = r0 * (1.0 + 0.35 * np.sin(a * U + ph) * np.cos(b * V) + 0.18 * np.sin(23 * U + 2 * V))
+    pos = c[:, None, :] + rad[..., None] * (np.cos(V)[..., None] * side[:, None, :] + np.sin(V)[..., None] * up[:, None, :])
+    pos[-1] = pos[0]
+    pos[:, -1] = pos[:, 0]
+    nrm = _grid_normals(pos, True, True)
+    uv = np.stack([U / (2 * np.pi) * 6.0, V / (2 * np.pi)], -1)
+    return _grid_mesh(pos, nrm, uv, _patch_materials(nu, nv, mids, 9, 2))
+
+
+def _thin_sheets(budget, rng, mids, count=2, thickness=0.004):
+    """curved sheets with a front and a back layer a few thousandths apart (thin shells with open rims)"""
+    out = []
+    per = budget // (2 * count)
+    for k in range(count):
+        nu, nv = _split(per, 1.6)
+        U, V = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+        sgn = 1.0 if k % 2 == 0 else -1.0
+        f1, f2, ph = rng.uniform(2, 5), rng.uniform(3, 7), rng.uniform(0, 6.28)
+        x = sgn * (0.25 + 0.75 * U)
+        y = 0.15 + 0.55 * V * (1.0 - 0.5 * U) + 0.06 * np.sin(f1 * np.pi * U + ph) * np.sin(f2 * np.pi * V)
+        z = -0.15 - 0.35 * U * U + 0.08 * np.cos(f2 * np.pi * U) * V + 0.25 * (k // 2)
+        pos = np.stack([x, y, z], -1)
+        nrm = _grid_normals(pos, False, False)
+        uv = np.stack([U * 3.0, V * 3.0], -1)
+        m = _patch_materials(nu, nv, mids, 3, 3, shift=k)
+        out.append(_grid_mesh(pos, nrm, uv, m))
+        out.append(_grid_mesh(pos - thickness * nrm, nrm, uv, m, flip=True))
+    return np.concatenate(out)
+
+
+def _shell(budget, rng, mids, radius, center, bumps, amp, squash=(1.0, 1.0, 1.0)):
+    """closed displaced lat/long shell without the degenerate pole rows"""
+    nu, nv = _split(budget, 0.5)                       # nu: latitude, nv: longitude
+    th = np.linspace(0.02, np.pi - 0.02, nu + 1)
+    ph = np.linspace(0.0, 2.0 * np.pi, nv + 1)
+    TH, PH = np.meshgrid(th, ph, indexing="ij")
+    disp = np.zeros_like(TH)
+    for _ in range(bumps):
+        disp += rng.uniform(0.3, 1.0) * np.sin(rng.randint(1, 9) * PH + rng.uniform(0, 6.28)) * np.sin(rng.randint(1, 7) * TH + rng.uniform(0, 6.28))
+    r = radius * (1.0 + amp * disp / max(bumps, 1))
+    d = np.stack([np.sin(TH) * np.cos(PH), np.cos(TH), np.sin(TH) * np.sin(PH)], -1)
+    pos = d * r[..., None] * np.asarray(squash) + np.asarray(center)
+    pos[:, -1] = pos[:, 0]
+    nrm = -_grid_normals(pos, False, True)
+    uv = np.stack([PH / (2 * np.pi) * 2.0, TH / np.pi * 2.0], -1)
+    return _grid_mesh(pos, nrm, uv, _patch_materials(nu, nv, mids, 4, 5), flip=True)
+
+
+def _beads(budget, rng, mids, count, radius, path):
+    """many small, finely tessellated shells strung along a path (the small end of the triangle-size range);
+    neighbours overlap, and all of them dig into whatever the path runs through"""
+    out = []
+    per = budget // count
+    for k in range(count):
+        c = path(k / float(count))
+        out.append(_shell(per, rng, [mids[k % len(mids)]], radius * rng.uniform(0.7, 1.3), c, 3, 0.25))
+    return np.concatenate(out)
+
+
+def _coarse_slab(mids, y=-0.42, half=1.25, n=2):
+    """a few very large triangles (the big end of the size range): an n x n grid plate under the model"""
+    g = np.linspace(-half, half, n + 1)
+    X, Z = np.meshgrid(g, g, indexing="ij")
+    pos = np.stack([X, np.full_like(X, y), Z], -1)
+    nrm = np.tile(np.array([0.0, 1.0, 0.0]), X.shape + (1,))
+    uv = np.stack([(X + half) / (2 * half) * 4, (Z + half) / (2 * half) * 4], -1)
+    return _grid_mesh(pos, nrm, uv, _patch_materials(n, n, mids, n, n), flip=True)
+
+
+def _ribbon(triangles, rng, mids, width=0.012, turns=9.0):
+    """a narrow strip of exactly `triangles` (even) small triangles spiralling around the model"""
+    nq = triangles // 2
+    if nq <= 0:
+        return np.zeros(0, dtype=TRI_DTYPE)
+    t = np.linspace(0.0, 1.0, nq + 1)
+    ang = 2 * np.pi * turns * t
+    r = 0.95 - 0.35 * t
+    c = np.stack([r * np.cos(ang), -0.35 + 0.9 * t, r * np.sin(ang)], -1)
+    up = np.array([0.0, 1.0, 0.0])
+    pos = np.stack([c, c + width * up], 1)                       # (nq+1, 2, 3)
+    nrm = np.stack([np.cos(ang), np.zeros_like(ang), np.sin(ang)], -1)
+    nrm = np.stack([nrm, nrm], 1)
+    uv = np.stack([np.stack([t * 40, np.zeros_like(t)], -1), np.stack([t * 40, np.ones_like(t)], -1)], 1)
+    return _grid_mesh(pos, nrm, uv, _patch_materials(nq, 1, mids, 16, 1))
+
+
+def composite_mesh(style, total, seed, trs, material_ids, center=(0.0, 0.0, 0.0), radius=1.0, squash=(1.0, 1.0, 1.0), tilt=(0.0, 0.0)):
+    """Seeded stand-in model of exactly `total` (even) triangles for a scene class whose asset is not distributed.
+    Unlike a single displaced sphere it has what scanned and modelled assets have and what makes a BVH work for its
+    living: deep concavities and parts that pass close to each other (knot tube), thin two-layer shells with open rims,
+    nested closed shells (an outer one around an inner one, so rays enter, cross a gap and hit again), parts that
+    intersect each other (beads dug into the tube), and triangle edges from about 1 down to about 0.005 of the model
+    radius (a coarse plate, beads of a few hundred tiny triangles each).  style picks the mix:
+      dragon  one knot, two wings, nested core, beads along the knot
+      chess   a coarse board and 32 pieces (stacked nested shells + beads) on an 8 x 4 + 8 x 4 layout
+      vehicle (911 / halo class) a big thin two-layer hull, four knot "wheels", nested interior, many beads
+    material_ids are spread over the parts in patches; id [1] (the transmissive material of the stand-in material set)
+    goes to the outer nested shell."""
+    rng = np.random.RandomState(seed)
+    mids = list(material_ids)
+    glass = [mids[1 % len(mids)]]
+    parts = []
+    slab = _coarse_slab(mids, n=2 if style != "chess" else 8)
+    budget = total - len(slab)
+    if style == "dragon":
+        parts.append(_knot_tube(int(budget * 0.42), rng, mids))
+        parts.append(_thin_sheets(int(budget * 0.16), rng, mids, count=2))
+        parts.append(_shell(int(budget * 0.10), rng, glass, 0.30, (0.0, 0.05, 0.0), 6, 0.35))
+        parts.append(_shell(int(budget * 0.06), rng, mids[2:] or mids, 0.17, (0.02, 0.05, 0.0), 5, 0.5))
+        knot = lambda t: np.array([(0.62 + 0.26 * np.cos(6 * np.pi * t)) * np.cos(4 * np.pi * t), 0.30 * np.sin(6 * np.pi * t) + 0.12,
+                                   (0.62 + 0.26 * np.cos(6 * np.pi * t)) * np.sin(4 * np.pi * t)])
+        parts.append(_beads(int(budget * 0.22), rng, mids, 60, 0.035, knot))
+    elif style == "chess":
+        per_piece = int(budget * 0.97) // 32
+        for k in range(32):
+            col, row = k % 8, k // 8
+            cx = (col - 3.5) * 0.27
+            cz = (row - 1.5) * 0.27 * (1.0 if row < 2 else 1.0) + (0.55 if row >= 2 else -0.55) * 0.0
+            cz = (-0.95 + 0.27 * row) if row < 2 else (0.41 + 0.27 * (row - 2))
+            h = 0.16 + 0.05 * ((k * 7) % 5)
+            m = [mids[(k + j) % len(mids)] for j in range(3)]
+            piece = [_shell(int(per_piece * 0.30), rng, m[:1], 0.105, (cx, -0.42 + 0.07, cz), 2, 0.15, squash=(1.0, 0.55, 1.0)),
+                     _shell(int(per_piece * 0.25), rng, m[1:2], 0.07, (cx, -0.42 + 0.07 + h * 0.5, cz), 3, 0.3, squash=(1.0, 1.8, 1.0)),
+                     _shell(int(per_piece * 0.15), rng, glass if k % 5 == 0 else m[2:3], 0.085, (cx, -0.42 + 0.09 + h, cz), 4, 0.35),
+                     _shell(int(per_piece * 0.10), rng, m[:1], 0.05, (cx, -0.42 + 0.09 + h, cz), 3, 0.4)]      # nested in the head
+            ring = lambda t, cx=cx, cz=cz, h=h: np.array([cx + 0.09 * np.cos(2 * np.pi * t), -0.42 + 0.05 + h * 0.8, cz + 0.09 * np.sin(2 * np.pi * t)])
+            piece.append(_beads(int(per_piece * 0.20), rng, m, 10, 0.018, ring))
+            parts.append(np.concatenate(piece))
+    else:
+        parts.append(_thin_sheets(int(budget * 0.10), rng, mids, count=4, thickness=0.003))
+        hull = _shell(int(budget * 0.22), rng, glass + mids[2:5], 0.78, (0.0, 0.0, 0.0), 8, 0.22, squash=(1.0, 0.42, 0.55))
+        inner = _shell(int(budget * 0.12), rng, mids, 0.76, (0.0, 0.0, 0.0), 8, 0.22, squash=(1.0, 0.40, 0.53))     # second layer close inside the first
+        parts += [hull, inner]
+        for w in range(4):
+            wheel = _knot_tube(int(budget * 0.07), rng, mids, p=1, q=int(5 + w), r0=0.10)
+            for f in ("v0", "v1", "v2"):
+                wheel[f] = (wheel[f] * np.array([0.28, 0.28, 0.28]) + np.array([0.5 * (1 if w % 2 else -1), -0.3, 0.36 * (1 if w // 2 else -1)])).astype(np.float32)
+            parts.append(wheel)
+        parts.append(_shell(int(budget * 0.08), rng, mids, 0.3, (0.1, 0.0, 0.0), 6, 0.5))
+        parts.append(_knot_tube(int(budget * 0.08), rng, mids, p=3, q=4, r0=0.05))
+        line = lambda t: np.array([-0.75 + 1.5 * t, 0.18 + 0.1 * np.sin(9 * t), 0.30 * np.sin(25 * t)])
+        parts.append(_beads(int(budget * 0.11), rng, mids, 160, 0.02, line))
+    used = len(slab) + sum(len(q) for q in parts)
+    rest = total - used
+    assert rest >= 0 and rest % 2 == 0, (total, used)
+    parts.append(_ribbon(rest, rng, mids))
+    tris = np.concatenate([slab] + parts)
+    assert len(tris) == total
+    # model frame -> turned towards the camera (tilt: degrees about x, then about y) -> the place the scene wants
+    # it, then the object's TRS baked in as the glTF import bakes it
+    sq = np.asarray(squash, np.float64)
+    ctr = np.asarray(center, np.float64)
+    ax, ay = np.radians(tilt[0]), np.radians(tilt[1])
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    R = Ry @ Rx
+    for fv, fn in (("v0", "n0"), ("v1", "n1"), ("v2", "n2")):
+        local = (tris[fv].astype(np.float64) @ R.T) * radius * sq + ctr
+        nl = (tris[fn].astype(np.float64) @ R.T) / sq
+        nl /= np.maximum(np.linalg.norm(nl, axis=1, keepdims=True), 1e-30)
+        P, N = _bake(local, nl, trs)
+        tris[fv], tris[fn] = P, N
+    return tris
 
 
 def cube_mesh(trs, material_id):
@@ -278,11 +510,11 @@ def metal_rough_texture(size, seed):
 
 # name -> (triangles target, #mesh materials, textured?, env?, grid)
 _ASSET_CLASS = {
-    "dragon": dict(grid=(260, 261), nmat=6, textured=False, env=True, env_intensity=0.6),     # 135 200 tris (README: 134 995)
-    "chess": dict(grid=(866, 867), nmat=18, textured=True, env=True, env_intensity=0.7),      # 1 499 912 tris (README: 1.5 M)
-    "p911": dict(grid=(1225, 1226), nmat=16, textured=True, env=True, env_intensity=3.0),     # 3.0 M tris (multi-million class)
-    "halo": dict(grid=(1225, 1226), nmat=13, textured=True, env=True, env_intensity=1.0),
-    "duck": dict(grid=(46, 47), nmat=1, textured=True, env=True, env_intensity=1.0),          # 4 232 tris (Duck.glb: 4 212)
+    "dragon": dict(grid=(260, 261), total=135200, style="dragon", nmat=6, textured=False, env=True, env_intensity=0.6),     # README: 134 995
+    "chess": dict(grid=(866, 867), total=1499912, style="chess", nmat=18, textured=True, env=True, env_intensity=0.7),      # README: 1.5 M
+    "p911": dict(grid=(1225, 1226), total=3001250, style="vehicle", nmat=16, textured=True, env=True, env_intensity=3.0),   # multi-million class
+    "halo": dict(grid=(1225, 1226), total=3001250, style="vehicle", nmat=13, textured=True, env=True, env_intensity=1.0),
+    "duck": dict(grid=(46, 47), nmat=1, textured=True, env=True, env_intensity=1.0),          # 4 232 tris blob (the real Duck.glb: make_duck_scene)
 }
 
 
@@ -324,12 +556,44 @@ def make_scene(name, res=None, depth=None, directory=None, tex_size=1024, env_si
         M2 = M @ M
         s2 = abs(np.linalg.det(M2[:3, :3])) ** (1.0 / 3.0)
         centre = np.linalg.solve(M2, np.array([0.0, 5.0, 0.0, 1.0]))[:3]
-        tris = blob_mesh(g[0], g[1], seed=1, trs=trs, material_ids=ids, center=tuple(centre), squash=(1.25, 1.0, 0.8),
-                         radius=5.5 / s2, bumps=10, amplitude=0.45)
+        if grid is None and "style" in cfg:
+            # full size: the composite model (knot tube, thin shells, nested shells, beads, coarse plate)
+            tris = composite_mesh(cfg["style"], cfg["total"], seed=1, trs=trs, material_ids=ids, center=tuple(centre),
+                                  radius=7.5 / s2, squash=(1.25, 1.0, 1.0),
+                                  tilt={"dragon": (65.0, 15.0), "chess": (38.0, 0.0), "vehicle": (25.0, 35.0)}[cfg["style"]])
+        else:
+            # a forced grid (small test scenes): one displaced closed blob of 2 * n_lon * (n_lat - 1) triangles
+            tris = blob_mesh(g[0], g[1], seed=1, trs=trs, material_ids=ids, center=tuple(centre), squash=(1.25, 1.0, 0.8),
+                             radius=5.5 / s2, bumps=10, amplitude=0.45)
         sc.add_mesh(tris, *trs)
         want_env = cfg["env"] if env is None else env
         if want_env:
             sc.set_envmap(sky_hdr(env_size[0], env_size[1]), cfg["env_intensity"])
     elif env:
         sc.set_envmap(sky_hdr(env_size[0], env_size[1]), 1.0)
+    return sc
+
+
+GOLDEN_DUCK = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "Duck.glb")
+
+
+def make_duck_scene(res=None, depth=None, directory=None, glb=None, env_size=(2048, 1024)):
+    """scenes/duck.json with the reference's own gltf/Duck.glb (kept as a data fixture under tests/golden) through
+    the glTF import.  The scene file names an environment map the reference does not distribute and has no light
+    geometry, so a procedural sky stands in for the map."""
+    d = scene_dict("duck")
+    d["Objects"][0]["FILE"] = glb or GOLDEN_DUCK
+    directory = directory or os.path.join(tempfile.gettempdir(), "mi_pathtrace_scenes_%d" % os.getuid())
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, "duck_real.json")
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(d, f, indent=1)
+    os.replace(tmp, path)
+    sc = Scene(path)
+    if res is not None:
+        sc.set_resolution(*res)
+    if depth is not None:
+        sc.set_depth(depth)
+    sc.set_envmap(sky_hdr(env_size[0], env_size[1]), 1.0)
     return sc
