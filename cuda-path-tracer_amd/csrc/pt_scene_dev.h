@@ -382,13 +382,21 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
         int sp = tv.sp;
+        if (sp + 3 <= kLdsStack) {
+            /* the common case: all three pushes fit the LDS part of the stack, no bounds to look at */
+#define PT_PUSH_LDS(k)                                                                               \
+            if (tk[k] < INF) { stack[sp * kBlock] = rk[k]; stack[(kLdsStack + sp) * kBlock] = __float_as_int(tk[k]); sp++; }
+            PT_PUSH_LDS(3) PT_PUSH_LDS(2) PT_PUSH_LDS(1)
+#undef PT_PUSH_LDS
+        } else {
 #define PT_PUSH(k)                                                                                   \
-        if (tk[k] < INF) {                                                                           \
-            if (sp < kLdsStack) { stack[sp * kBlock] = rk[k]; stack[(kLdsStack + sp) * kBlock] = __float_as_int(tk[k]); sp++; } \
-            else if (sp < kLdsStack + kOverflowStack) { ovRef[sp - kLdsStack] = rk[k]; ovT[sp - kLdsStack] = tk[k]; sp++; }     \
-        }
-        PT_PUSH(3) PT_PUSH(2) PT_PUSH(1)
+            if (tk[k] < INF) {                                                                       \
+                if (sp < kLdsStack) { stack[sp * kBlock] = rk[k]; stack[(kLdsStack + sp) * kBlock] = __float_as_int(tk[k]); sp++; } \
+                else if (sp < kLdsStack + kOverflowStack) { ovRef[sp - kLdsStack] = rk[k]; ovT[sp - kLdsStack] = tk[k]; sp++; }     \
+            }
+            PT_PUSH(3) PT_PUSH(2) PT_PUSH(1)
 #undef PT_PUSH
+        }
         tv.sp = sp;
         if (COUNT && (uint32_t)sp > cnt.maxSp) cnt.maxSp = (uint32_t)sp;
         if (tk[0] < INF) { tv.ref = rk[0]; return true; }
@@ -415,6 +423,17 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
     }
     /* pop the next entry that can still hold a closer (or equal) hit */
     int sp = tv.sp;
+    if (sp <= kLdsStack) {
+        /* everything left is in LDS */
+        while (sp > 0) {
+            sp--;
+            const int r2 = stack[sp * kBlock];
+            const float t = __int_as_float(stack[(kLdsStack + sp) * kBlock]);
+            if (!(t > tv.closestT)) { tv.sp = sp; tv.ref = r2; return true; }
+        }
+        tv.sp = 0;
+        return false;
+    }
     while (sp > 0) {
         sp--;
         float t;

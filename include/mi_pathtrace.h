@@ -215,7 +215,7 @@ enum PtOption {
     PT_OPT_STAGE_TIMING = 3,     /* bracket every stage with HIP events (default 0);
                                     while on, a launch group stays on one stream    */
     PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
-    PT_OPT_USE_GRAPH = 5,        /* reserved (hipGraph replay); accepted, no effect */
+    PT_OPT_USE_GRAPH = 5,        /* hipGraph replay of an iteration: not supported, a non-zero value returns PT_EINVAL */
     PT_OPT_BATCH = 6             /* iterations that share one launch group in
                                     pt_trace_range (default 16, at most 512); results
                                     do not depend on it                              */

@@ -1,0 +1,116 @@
+/*
+ * pathtrace_mi355x.cpp — the file a maintainer of the reference adds in place of src/pathtrace.cu
+ * (+ intersections.cu, interactions.cu): the four functions of the reference's own src/pathtrace.h:8-11
+ * on top of libmi_pathtrace.so.  It is written against the REFERENCE's headers (scene.h, sceneStructs.h,
+ * utilities.h), not against this repository's host scene, and is compiled and run as such by
+ * oracle/Makefile (target _ref/ref_render) wherever the reference tree is present, so it cannot rot.
+ *
+ * Layout facts it relies on (checked by the static_asserts below and by tests/test_host_side.py):
+ * Material == PtMaterial (124 B), Triangle == PtTriangle (100 B), Camera == PtCamera (84 B).
+ */
+#include "pathtrace.h"              /* the reference's header, unchanged */
+#include "scene.h"
+#include <mi_pathtrace.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+static_assert(sizeof(Material) == sizeof(PtMaterial) && sizeof(Triangle) == sizeof(PtTriangle) && sizeof(Camera) == sizeof(PtCamera),
+              "the reference's PODs and the C ABI's must have one layout");
+
+static PtContext* ctx = nullptr;
+static Scene* hst_scene = nullptr;
+static GuiDataContainer* guiData = nullptr;
+
+static void die(const char* what)
+{
+    /* checkCUDAError (src/pathtrace.cu:27-48): print and leave */
+    fprintf(stderr, "%s failed: %s\n", what, pt_last_error());
+    exit(EXIT_FAILURE);
+}
+
+void InitDataContainer(GuiDataContainer* g) { guiData = g; }
+
+void pathtraceFree()
+{
+    if (ctx) pt_destroy(ctx);
+    ctx = nullptr;
+}
+
+void pathtraceInit(Scene* scene)
+{
+    pathtraceFree();
+    hst_scene = scene;
+    std::vector<PtGeom> geoms;
+    std::vector<PtMesh> meshes;
+    for (const Geom& g : scene->geoms) {
+        PtGeom o;
+        memset(&o, 0, sizeof(o));
+        o.type = (int32_t)g.type;                       /* SPHERE, CUBE, GLTF_MESH in one order on both sides */
+        o.materialid = g.type == GLTF_MESH ? -1 : g.materialid;      /* never assigned for glTF objects (src/scene.cpp:863-884) */
+        memcpy(o.translation, &g.translation, 12);
+        memcpy(o.rotation, &g.rotation, 12);
+        memcpy(o.scale, &g.scale, 12);
+        memcpy(o.transform, &g.transform, 64);
+        memcpy(o.inverseTransform, &g.inverseTransform, 64);
+        memcpy(o.invTranspose, &g.invTranspose, 64);
+        o.meshIndex = -1;
+        o.triangleStart = -1;
+        o.bvhIndex = -1;
+        if (g.type == GLTF_MESH && g.triangleCount > 0) {
+            /* Geom::meshData points at scene->meshes.back() of the moment it was loaded and dangles once a second
+             * model is pushed (src/scene.cpp:535-537): take the mesh by position instead, one per loaded model */
+            const MeshData& md = scene->meshes[meshes.size()];
+            PtMesh m;
+            memset(&m, 0, sizeof(m));
+            m.triangles = reinterpret_cast<const PtTriangle*>(md.triangles.data());
+            m.triangleCount = (int32_t)md.triangles.size();
+            /* nodes / triangleIndices stay null: pt_create runs BVH::build's algorithm itself.  A maintainer who keeps
+             * the reference's BVH objects hands their node and index arrays over here instead (BVHNode == PtBvhNode). */
+            o.meshIndex = (int32_t)meshes.size();
+            o.triangleCount = m.triangleCount;
+            meshes.push_back(m);
+        }
+        geoms.push_back(o);
+    }
+    std::vector<PtTexture> textures;
+    for (const Texture& t : scene->textures) {          /* host pixels as loadGLTFTexture left them (src/scene.cpp:44-90) */
+        PtTexture o;
+        o.data = t.data; o.width = t.width; o.height = t.height; o.components = t.components;
+        textures.push_back(o);
+    }
+    PtSceneDesc d;
+    memset(&d, 0, sizeof(d));
+    d.geoms = geoms.data(); d.geomCount = (int32_t)geoms.size();
+    d.materials = reinterpret_cast<const PtMaterial*>(scene->materials.data()); d.materialCount = (int32_t)scene->materials.size();
+    d.meshes = meshes.data(); d.meshCount = (int32_t)meshes.size();
+    d.textures = textures.data(); d.textureCount = (int32_t)textures.size();
+    /* HostEnvironmentMap::enabled / width / height are only written when the file loaded (src/scene.cpp:792-795) and
+     * are indeterminate otherwise: the pixel vector says whether there is a map */
+    const HostEnvironmentMap& e = scene->environmentMap;
+    if (!e.data.empty()) {
+        d.env.data = reinterpret_cast<const float*>(e.data.data());      /* already multiplied by the intensity (:810-817) */
+        d.env.width = e.width; d.env.height = e.height; d.env.intensity = e.intensity; d.env.enabled = 1;
+    }
+    memcpy(&d.camera, &scene->state.camera, sizeof(PtCamera));
+    d.traceDepth = scene->state.traceDepth;
+    d.iterations = (int32_t)scene->state.iterations;
+    if (pt_create(&d, /* device */ 0, &ctx) != PT_OK) die("pathtraceInit");
+    if (pt_set_option(ctx, PT_OPT_MATERIAL_SORT, MATERIAL_SORTING) != PT_OK) die("pathtraceInit");
+}
+
+void pathtrace(uchar4* pbo, int /* frame */, int iter)
+{
+    if (!ctx) { fprintf(stderr, "pathtrace: pathtraceInit has not been called\n"); exit(EXIT_FAILURE); }
+    if (pt_trace(ctx, iter) != PT_OK) die("pathtrace");
+    if (pbo && pt_display(ctx, iter, reinterpret_cast<uint8_t*>(pbo)) != PT_OK) die("pathtrace");      /* pbo: a device pointer, as the GL interop map yields */
+    /* the running sum goes back to the host after every iteration, as at src/pathtrace.cu:2913-2917 */
+    if (pt_download(ctx, reinterpret_cast<float*>(hst_scene->state.image.data())) != PT_OK) die("pathtrace");
+    if (guiData) {
+        PtStats s;
+        if (pt_stats(ctx, &s) != PT_OK) die("pathtrace");
+        guiData->TracedDepth = (int)s.lastDepth;        /* src/pathtrace.cu:2712-2715 */
+    }
+}

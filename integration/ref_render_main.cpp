@@ -1,0 +1,73 @@
+/*
+ * ref_render — headless stand-in for the reference's main.cpp around pathtrace_mi355x.cpp: the REFERENCE's scene
+ * loader (Scene::Scene, linked from the reference's own scene.cpp) feeds the reference-shaped pathtraceInit /
+ * pathtrace / pathtraceFree, which run on libmi_pathtrace.so.  Test infrastructure (built by oracle/Makefile into
+ * oracle/_ref/, only where the reference tree is present).
+ *
+ *   ref_render <scene.json> <iterations> <out.bin> [width height]
+ * writes width, height (int32) and the W*H*3 float running sum.
+ */
+#include "pathtrace.h"
+#include "scene.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+struct uchar4;
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: ref_render scene.json iterations out.bin [width height]\n"); return 2; }
+    Scene* scene = new Scene(std::string(argv[1]));
+    const int iterations = atoi(argv[2]);
+    Camera& cam = scene->state.camera;
+    if (argc >= 6) {
+        /* what a changed RES entry does in the loader (src/scene.cpp:886-917) */
+        cam.resolution.x = atoi(argv[4]);
+        cam.resolution.y = atoi(argv[5]);
+        float fovy = cam.fov.y;
+        float yscaled = tan(fovy * (PI / 180));
+        float xscaled = (yscaled * cam.resolution.x) / cam.resolution.y;
+        float fovx = (atan(xscaled) * 180) / PI;
+        cam.fov = glm::vec2(fovx, fovy);
+        cam.pixelLength = glm::vec2(2 * xscaled / (float)cam.resolution.x, 2 * yscaled / (float)cam.resolution.y);
+        scene->state.image.assign((size_t)cam.resolution.x * cam.resolution.y, glm::vec3());
+    }
+    /* main() and the first runCuda() of the reference (src/main.cpp:750-769, :788-807): the camera the kernels see */
+    glm::vec3 view = cam.view;
+    glm::vec3 viewXZ = glm::vec3(view.x, 0.0f, view.z);
+    glm::vec3 viewZY = glm::vec3(0.0f, view.y, view.z);
+    float phi = glm::acos(glm::dot(glm::normalize(viewXZ), glm::vec3(0, 0, -1)));
+    float theta = glm::acos(glm::dot(glm::normalize(viewZY), glm::vec3(0, 1, 0)));
+    float zoom = glm::length(cam.position - cam.lookAt);
+    glm::vec3 cameraPosition;
+    cameraPosition.x = zoom * sin(phi) * sin(theta);
+    cameraPosition.y = zoom * cos(theta);
+    cameraPosition.z = zoom * cos(phi) * sin(theta);
+    cam.view = -glm::normalize(cameraPosition);
+    glm::vec3 v = cam.view;
+    glm::vec3 u = glm::vec3(0, 1, 0);
+    glm::vec3 r = glm::cross(v, u);
+    cam.up = glm::cross(r, v);
+    cam.right = r;
+    cam.position = cameraPosition;
+    cameraPosition += cam.lookAt;
+    cam.position = cameraPosition;
+
+    GuiDataContainer gui;
+    InitDataContainer(&gui);
+    pathtraceFree();                                    /* src/main.cpp:814 */
+    pathtraceInit(scene);
+    for (int it = 1; it <= iterations; ++it) pathtrace(nullptr, 0, it);
+    FILE* f = fopen(argv[3], "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", argv[3]); return 2; }
+    int32_t wh[2] = { cam.resolution.x, cam.resolution.y };
+    fwrite(wh, 4, 2, f);
+    fwrite(scene->state.image.data(), 12, scene->state.image.size(), f);
+    fclose(f);
+    fprintf(stderr, "ref_render: %d iterations, traced depth %d\n", iterations, gui.TracedDepth);
+    pathtraceFree();
+    return 0;
+}

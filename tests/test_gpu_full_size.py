@@ -268,3 +268,38 @@ def test_allocation_failure_leaves_context_usable(pt, scenes, orc, gpu_ok):
     tr.clear()
     tr.trace_range(1, 3)
     tr.sync()
+
+
+def test_reference_loader_through_maintainer_shim_renders_the_same_image(pt, scenes, gpu_ok, tmp_path):
+    """oracle/_ref/ref_render = the reference's own Scene loader + integration/pathtrace_mi355x.cpp (the four functions
+    of the reference's pathtrace.h on this library) + a headless main that replays main.cpp's camera set-up.  Its running
+    sum must equal, bit for bit, what this repository's loader and Tracer give for the same scene file."""
+    import subprocess
+    render = os.path.join(os.path.dirname(ref.TOOL), "ref_render")
+    if not os.path.exists(render):
+        pytest.skip("oracle/_ref/ref_render is not built (the reference tree was absent at build time)")
+    d = scenes.scene_dict("duck")
+    d["Objects"][0]["FILE"] = DUCK
+    d["Objects"].append(dict(TYPE="cube", MATERIAL="light", TRANS=[0, 10, 0], ROTAT=[0, 0, 0], SCALE=[3, 0.3, 3]))
+    d["Objects"].append(dict(TYPE="sphere", MATERIAL="polished_gold", TRANS=[2.5, 1.5, 1.0], ROTAT=[0, 0, 0], SCALE=[2, 2, 2]))
+    d["Camera"]["EYE"] = [0.0, 2.5, 9.0]
+    d["Camera"]["LOOKAT"] = [0.0, 2.0, 0.0]
+    d.pop("EnvironmentMap", None)
+    p = tmp_path / "duck_shim.json"
+    p.write_text(json.dumps(d))
+    out = tmp_path / "sum.bin"
+    env = dict(os.environ)
+    env.pop("LD_BIND_NOW", None)
+    r = subprocess.run([render, str(p), "3", str(out), "96", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    raw = out.read_bytes()
+    w, h = np.frombuffer(raw[:8], np.int32)
+    theirs = np.frombuffer(raw[8:], np.float32).reshape(h, w, 3)
+    sc = pt.Scene(p)
+    sc.set_resolution(96, 64)
+    tr = pt.Tracer(sc)
+    for it in (1, 2, 3):
+        tr.trace(it)
+    mine = tr.image()
+    assert (w, h) == (96, 64) and float(mine.sum()) > 0
+    assert _same_bits(mine, theirs), "max abs diff %g" % np.nanmax(np.abs(mine - theirs))

@@ -293,6 +293,9 @@ def test_launch_shapes_and_largest_groups_bit_exact(pt, scenes, orc, gpu_ok):
     assert tr.stats().pathBounces == o.stats().pathBounces
     with pytest.raises(pt.PtError):
         tr.set_option(pt.PT_OPT_BATCH, 513)
+    with pytest.raises(pt.PtError, match="not supported"):
+        tr.set_option(pt.PT_OPT_USE_GRAPH, 1)
+    tr.set_option(pt.PT_OPT_USE_GRAPH, 0)
 
 
 def test_depth_one_and_tiny_images(pt, scenes, orc, gpu_ok):

@@ -287,3 +287,17 @@ def test_image_writers_equal_the_reference_writers(pt, tmp_path):
         a, b = open(theirs, "rb").read(), (tmp_path / ("mine%d.hdr" % k)).read_bytes()
         assert b"# Written by stb_image_write.h\n" in a and b"# Written by libmi_pathtrace\n" in b      # the one line that differs
         assert a.replace(b"stb_image_write.h", b"X") == b.replace(b"libmi_pathtrace", b"X"), k
+
+
+def test_maintainer_shim_compiles_against_the_reference_headers():
+    """integration/pathtrace_mi355x.cpp (the file INTEGRATION.md tells a maintainer to add) is compiled by oracle/Makefile
+    against the reference's own pathtrace.h / scene.h / sceneStructs.h and linked with the reference's loader and
+    libmi_pathtrace.so; what it renders is checked on the GPU (tests/test_gpu_full_size.py)."""
+    render = os.path.join(os.path.dirname(ref.TOOL), "ref_render")
+    if os.path.isdir(ref.REFERENCE):
+        assert os.path.exists(render), "run `make -C oracle`"
+    text = open(os.path.join(os.path.dirname(HERE), "integration", "pathtrace_mi355x.cpp")).read()
+    for name in ("void InitDataContainer(GuiDataContainer*", "void pathtraceInit(Scene*", "void pathtraceFree()", "void pathtrace(uchar4*"):
+        assert name in text
+    doc = open(os.path.join(os.path.dirname(HERE), "INTEGRATION.md")).read()
+    assert "integration/pathtrace_mi355x.cpp" in doc

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Per-kernel hardware-counter summary of one workload from the passes of tools/profile_r02.sh.
+
+    python tools/pmc_workload.py <dir with sq/ sq2/ l2/ fetch/ write/ and *_bench.json> <workload>
+
+Writes profiles/pmc_<workload>.json (per-ray figures bench.py reads for its roofline) and prints a table.
+
+Only the dispatches of the last pass of bench.py are used: the event-bracketed pass that runs every launch group on
+one stream (steps x depth launches of each traversal kernel).  Counter arithmetic:
+  issue utilisation  = SQ_INSTS_VALU x 4 cycles / (SIMDs x GRBM_GUI_ACTIVE-equivalent cycles) is not used (clock varies);
+                       instead SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x SIMDs per SE share) is reported as measured by
+                       the SQ itself: ACTIVE_INST_VALU / WAVE_CYCLES gives the share of a resident wave's time in which
+                       it issues vector ALU work; multiplied by the resident waves per SIMD it is the SIMD's issue share
+  lane utilisation   = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)
+  lane instructions  = SQ_INSTS_VALU x 64 x lane utilisation
+  HBM bytes          = (2 x FETCH_SIZE + WRITE_SIZE) x 1024   (FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950)
+  L2 hit rate        = TCC_HIT / (TCC_HIT + TCC_MISS)
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = [("k_trace<0, false>", "k_trace(closest)"), ("k_trace<1, false>", "k_trace(shadow)"), ("k_shade<false, false>", "k_shade"),
+         ("k_prims<false, false>", "k_prims"), ("k_shade<false, true>", "k_shade(sparse form)"), ("k_prims<false, true>", "k_prims(sparse form)"),
+         ("k_camera", "k_camera")]
+
+
+def nice(kernel):
+    for pat, n in NAMES:
+        if pat in kernel:
+            return n
+    return None
+
+
+def load(root):
+    """{kernel: {dispatch id: {counter: value, '_ns': duration}}}"""
+    d = defaultdict(lambda: defaultdict(dict))
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = nice(r["Kernel_Name"])
+            if not k:
+                continue
+            e = d[k][int(r["Dispatch_Id"])]
+            e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            e["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return d
+
+
+def last_sum(per_dispatch, n):
+    ids = sorted(per_dispatch)[-n:]
+    out = defaultdict(float)
+    for i in ids:
+        for c, v in per_dispatch[i].items():
+            out[c] += v
+    out["_launches"] = len(ids)
+    return out
+
+
+def main():
+    base, workload = sys.argv[1], sys.argv[2]
+    bench = json.loads(open(os.path.join(base, "sq_bench.json")).read().strip().splitlines()[-1])
+    rl = bench["roofline"]
+    depth, steps = bench["config"]["depth"], bench["steps"]
+    n = steps * depth
+    rays_closest = rl["rays_per_launch"] * rl["launches"]
+    spp = bench["config"]["spp_per_step_per_gpu"] * steps
+    rays = {"k_trace(closest)": rays_closest, "k_trace(shadow)": bench["config"]["shadow_rays_per_spp"] * spp}
+    passes = {p: load(os.path.join(base, p)) for p in ("sq", "sq2", "l2", "fetch", "write")}
+    res = {"_workload": workload, "_bench_line_of_the_sq_pass": {k: bench[k] for k in ("value", "ms_per_step")},
+           "_method": "rocprofv3 --pmc, one pass per counter group (tools/profile_r02.sh), sums over the last %d dispatches of each kernel "
+                      "(the single-stream pass of bench.py --steps %d); see tools/pmc_workload.py for the arithmetic" % (n, steps)}
+    lines = []
+    for _pat, k in NAMES:
+        if k not in passes["sq"]:
+            continue
+        nk = n if "trace" in k or k in ("k_shade", "k_prims") else steps
+        sq, sq2, l2 = last_sum(passes["sq"][k], nk), last_sum(passes["sq2"].get(k, {}), nk), last_sum(passes["l2"].get(k, {}), nk)
+        fe, wr = last_sum(passes["fetch"].get(k, {}), nk), last_sum(passes["write"].get(k, {}), nk)
+        e = {"launches_summed": int(sq["_launches"]), "ms_total_under_counters": round(sq["_ns"] / 1e6, 3)}
+        act, wavecyc = sq.get("SQ_ACTIVE_INST_VALU", 0.0), sq.get("SQ_WAVE_CYCLES", 0.0)
+        lane = sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / (act * 64.0) if act else None
+        e["valu_wave_instructions"] = sq.get("SQ_INSTS_VALU")
+        e["valu_lane_utilisation"] = round(lane, 4) if lane else None
+        e["valu_share_of_wave_time"] = round(act / wavecyc, 4) if wavecyc else None
+        e["wait_any_share_of_wave_time"] = round(sq.get("SQ_WAIT_ANY", 0.0) / wavecyc, 4) if wavecyc else None
+        e["wait_inst_share_of_wave_time"] = round(sq.get("SQ_WAIT_INST_ANY", 0.0) / wavecyc, 4) if wavecyc else None
+        busy = sq.get("SQ_BUSY_CYCLES", 0.0)
+        e["mean_resident_waves_x_busy"] = round(wavecyc / busy, 3) if busy else None
+        # time-based issue utilisation: wave-instructions x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz)
+        secs = sq["_ns"] * 1e-9
+        e["valu_issue_utilisation"] = round(sq.get("SQ_INSTS_VALU", 0.0) * 4.0 / (1024.0 * secs * 2.4e9), 4) if secs else None
+        if lane and k in rays and rays[k] > 0:
+            e["valu_lane_instructions_per_ray"] = round(sq.get("SQ_INSTS_VALU", 0.0) * 64.0 * lane / rays[k], 1)
+            e["valu_wave_instructions_per_ray_x64"] = round(sq.get("SQ_INSTS_VALU", 0.0) * 64.0 / rays[k], 1)
+        hit, miss = l2.get("TCC_HIT_sum", 0.0), l2.get("TCC_MISS_sum", 0.0)
+        e["l2_hit_rate"] = round(hit / (hit + miss), 4) if hit + miss else None
+        e["l2_requests"] = l2.get("TCC_REQ_sum")
+        e["ta_busy_avr"] = round(l2.get("TA_BUSY_avr", 0.0) / max(l2["_launches"], 1), 2) if l2.get("_launches") else None
+        hbm = (2.0 * fe.get("FETCH_SIZE", 0.0) + wr.get("WRITE_SIZE", 0.0)) * 1024.0
+        e["hbm_bytes"] = round(hbm)
+        e["hbm_read_bytes(2xFETCH_SIZE)"] = round(2.0 * fe.get("FETCH_SIZE", 0.0) * 1024.0)
+        e["hbm_write_bytes"] = round(wr.get("WRITE_SIZE", 0.0) * 1024.0)
+        if k in rays and rays[k] > 0:
+            e["hbm_bytes_per_ray"] = round(hbm / rays[k], 2)
+        fsec = fe["_ns"] * 1e-9 if fe.get("_ns") else 0
+        e["hbm_gbs_under_counters"] = round(hbm / fsec / 1e9, 1) if fsec else None
+        for c in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_SMEM"):
+            if c in sq2:
+                e[c.lower()] = sq2[c]
+        res[k] = e
+        lines.append("%-22s launches %3d  %9.2f ms  VALU issue %5.1f%%  lanes %5.1f%%  VALU share of wave time %5.1f%%  waiting %5.1f%%  L2 hit %5.1f%%  HBM %8.2f GB (%6.1f GB/s)" % (
+            k, e["launches_summed"], e["ms_total_under_counters"], 100 * (e["valu_issue_utilisation"] or 0), 100 * (lane or 0),
+            100 * (e["valu_share_of_wave_time"] or 0), 100 * (e["wait_any_share_of_wave_time"] or 0), 100 * (e["l2_hit_rate"] or 0),
+            hbm / 1e9, e["hbm_gbs_under_counters"] or 0))
+    out = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    json.dump(res, open(out, "w"), indent=1)
+    txt = os.path.join(ROOT, "profiles", "r02_units_%s.txt" % workload)
+    open(txt, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    print("wrote", out, "and", txt)
+
+
+if __name__ == "__main__":
+    main()
