@@ -389,6 +389,130 @@ struct UpperTree {
     }
 };
 
+/* Insertion-based optimisation of the rebuilt hierarchy (after Bittner, Hapala, Havran: "Fast insertion-based
+ * optimization of bounding volume hierarchies", 2013).  The top-down binned build decides every split once, with the
+ * coarse view it has at that level; here subtrees are taken out and put back where they add the least surface area,
+ * largest boxes first, for a few passes.  Only the tree ABOVE the reference's leaves moves — the leaves, their boxes
+ * and so the traversal's results stay what they are; what changes is how many boxes a ray tests on its way down. */
+struct UpperOptimizer {
+    UpperTree& U;
+    std::vector<int> parent;
+    int root;
+    explicit UpperOptimizer(UpperTree& u, int r) : U(u), parent(u.nodes.size(), -1), root(r)
+    {
+        for (size_t i = 0; i < U.nodes.size(); ++i)
+            if (U.nodes[i].leaf < 0) { parent[U.nodes[i].left] = (int)i; parent[U.nodes[i].right] = (int)i; }
+    }
+    static float area(const UpperTree::Node& n) { return UpperTree::halfArea(n.lo, n.hi); }
+    static float unionArea(const UpperTree::Node& a, const UpperTree::Node& b)
+    {
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(a.lo[k], b.lo[k]); hi[k] = std::max(a.hi[k], b.hi[k]); }
+        return UpperTree::halfArea(lo, hi);
+    }
+    void refitFrom(int i)
+    {
+        for (; i >= 0; i = parent[i]) {
+            UpperTree::Node& n = U.nodes[i];
+            const UpperTree::Node &a = U.nodes[n.left], &b = U.nodes[n.right];
+            float lo[3], hi[3];
+            bool same = true;
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(a.lo[k], b.lo[k]); hi[k] = std::max(a.hi[k], b.hi[k]);
+                same = same && lo[k] == n.lo[k] && hi[k] == n.hi[k];
+            }
+            if (same) break;                       /* nothing changes further up either */
+            memcpy(n.lo, lo, 12); memcpy(n.hi, hi, 12);
+        }
+    }
+    /* take subtree n out (its parent p disappears, the sibling moves up); returns the freed node p */
+    int detach(int n)
+    {
+        const int p = parent[n], g = parent[p];
+        const int sib = U.nodes[p].left == n ? U.nodes[p].right : U.nodes[p].left;
+        if (U.nodes[g].left == p) U.nodes[g].left = sib; else U.nodes[g].right = sib;
+        parent[sib] = g;
+        refitFrom(g);
+        return p;
+    }
+    /* the node x beside which n costs least: area(x + n) plus what the boxes above x grow by; branch and bound over
+     * the growth accumulated on the way down */
+    int bestSibling(int n)
+    {
+        const UpperTree::Node& N = U.nodes[n];
+        const float areaN = area(N);
+        struct Item { float inherited; int node; };
+        auto cmp = [](const Item& a, const Item& b) { return a.inherited > b.inherited; };
+        std::vector<Item> heap;
+        heap.push_back({ 0.0f, root });
+        float best = 3.4e38f;
+        int bestNode = root;
+        int visited = 0;
+        while (!heap.empty() && visited < 4096) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            Item it = heap.back();
+            heap.pop_back();
+            if (it.inherited + areaN >= best) break;            /* no place below can beat the best found */
+            ++visited;
+            const UpperTree::Node& X = U.nodes[it.node];
+            const float direct = unionArea(X, N);
+            const float total = it.inherited + direct;
+            if (total < best) { best = total; bestNode = it.node; }
+            if (X.leaf < 0) {
+                const float down = it.inherited + (direct - area(X));   /* growth of X if n goes somewhere below it */
+                if (down + areaN < best) {
+                    heap.push_back({ down, X.left }); std::push_heap(heap.begin(), heap.end(), cmp);
+                    heap.push_back({ down, X.right }); std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+            }
+        }
+        return bestNode;
+    }
+    void attach(int n, int x, int freeNode)
+    {
+        const int g = parent[x];
+        UpperTree::Node& P = U.nodes[freeNode];
+        P.leaf = -1; P.left = x; P.right = n;
+        for (int k = 0; k < 3; ++k) { P.lo[k] = std::min(U.nodes[x].lo[k], U.nodes[n].lo[k]); P.hi[k] = std::max(U.nodes[x].hi[k], U.nodes[n].hi[k]); }
+        parent[freeNode] = g;
+        if (g < 0) root = freeNode;
+        else if (U.nodes[g].left == x) U.nodes[g].left = freeNode; else U.nodes[g].right = freeNode;
+        parent[x] = freeNode; parent[n] = freeNode;
+        refitFrom(g);
+    }
+    float cost() const
+    {
+        double c = 0.0;
+        std::vector<int> st{ root };
+        while (!st.empty()) { int i = st.back(); st.pop_back(); const UpperTree::Node& n = U.nodes[i]; if (n.leaf < 0) { c += area(n); st.push_back(n.left); st.push_back(n.right); } }
+        return (float)(c / area(U.nodes[root]));
+    }
+    /* passes over the nodes in order of decreasing box area; `budget` bounds the number of reinsertions per pass */
+    int run(int passes, size_t budget)
+    {
+        for (int pass = 0; pass < passes; ++pass) {
+            std::vector<std::pair<float, int>> cand;
+            cand.reserve(U.nodes.size());
+            for (size_t i = 0; i < U.nodes.size(); ++i) {
+                const int p = parent[i];
+                if ((int)i == root || p < 0 || p == root) continue;       /* the root's children stay: their parent cannot be freed */
+                cand.push_back({ area(U.nodes[i]), (int)i });
+            }
+            const size_t take = std::min(budget, cand.size());
+            std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
+            for (size_t k = 0; k < take; ++k) {
+                const int n = cand[k].second;
+                const int p = parent[n];
+                if (p < 0 || p == root || n == root) continue;          /* the tree moved since the list was made */
+                const int freeNode = detach(n);
+                const int x = bestSibling(n);
+                attach(n, x, freeNode);
+            }
+        }
+        return root;
+    }
+};
+
 /* Turns the host BVH (40-byte binary nodes + index array, src/bvh.h:55-65) into the device
  * layout: triangles permuted into leaf order, each stamped with its rank in the reference's
  * visit order (right subtree first, src/intersections.cu:379-384), and the inner levels
@@ -597,6 +721,13 @@ int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nn
             U.nodes.reserve(2 * U.leaves.size());
             if (U.leaves.size() >= 2) {
                 int root = U.build(0, (int)U.leaves.size(), 0);
+                static const int optPasses = [] { const char* e = getenv("PT_UPPER_OPT"); return e ? atoi(e) : 3; }();
+                if (optPasses > 0 && U.leaves.size() >= 8) {
+                    UpperOptimizer O(U, root);
+                    const float before = getenv("PT_DEBUG_TAIL") ? O.cost() : 0.0f;
+                    root = O.run(optPasses, std::min<size_t>(U.nodes.size(), 600000));
+                    if (getenv("PT_DEBUG_TAIL")) fprintf(stderr, "[pt] upper tree over %zu leaves: surface-area cost %.2f -> %.2f after %d reinsertion passes\n", U.leaves.size(), before, O.cost(), optPasses);
+                }
                 F.collapseUpper(U, root, 0);
                 done = 3 * fm.depth4 + 1 <= kLdsStack + kOverflowStack;
                 if (!done) { fm.nodes.clear(); fm.depth4 = 0; }      /* too deep: fall back to the host topology */
