@@ -384,6 +384,22 @@ def main():
                    "sample": "%d spp of the same workload (%d path-bounces, %.1f s) on the CPU restatement of the reference's loop, "
                              "OpenMP over queue slots, libm arithmetic" % (cpu_spp, os_.pathBounces, c1 - c0)}
             o.close()
+            # the reference's OWN intersection code (src/intersections.cu + src/bvh.cpp, compiled where they lie as
+            # oracle/_ref/ref_tool) on the camera rays of one iteration: the closest-hit stage alone, in rays per second
+            try:
+                import ref_binding as refb
+                if refb.available() and st.launchesTrace > 0:
+                    ro, rd = tr.camera_rays(1)
+                    m = min(len(ro), 400000)
+                    timing = {}
+                    refb.intersect(sc, ro[:m], rd[:m], timing=timing)
+                    if timing:
+                        cpu["reference_closest_hit"] = {"value": round(timing["rays"] / timing["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": timing["threads"],
+                                                        "kind": "reference",
+                                                        "sample": "%d camera rays of iteration 1 through the reference's computeIntersectionsBVH loop "
+                                                                  "(its own boxIntersectionTest / meshIntersectionTestBVH / BVH::build), OpenMP over rays" % timing["rays"]}
+            except Exception as e:          # the checker's tool is optional
+                cpu["reference_closest_hit"] = {"error": str(e)[:200]}
 
         pb_spp = st.pathBounces / max(spp_rank, 1)
         out = {"metric": "Mpaths*bounce/s (%s)" % args.workload, "value": round(value, 3), "unit": "Mpaths*bounce/s",

@@ -27,6 +27,8 @@
 #include "intersections.h"
 #include "stb_image.h"
 
+#include <omp.h>
+
 #include <cfloat>
 #include <cstdint>
 #include <cstdio>
@@ -131,6 +133,7 @@ static void runRays(const Loaded& L, const char* raysPath, const char* outPath, 
     const size_t n = rb.size() / 24;
     const float* r = (const float*)rb.data();
     std::vector<HitRec> hits(n);
+    const double t0 = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 256)
     for (long long i = 0; i < (long long)n; ++i) {
         Ray ray;
@@ -138,6 +141,9 @@ static void runRays(const Loaded& L, const char* raysPath, const char* outPath, 
         ray.direction = glm::vec3(r[6 * i + 3], r[6 * i + 4], r[6 * i + 5]);
         hits[(size_t)i] = closestHit(L, ray, useBvh);
     }
+    const double t1 = omp_get_wtime();
+    /* the closest-hit loop alone (no loading, no BVH build), for the CPU baseline of the benchmark */
+    printf("ref_tool isect: %zu rays in %.6f s on %d threads\n", n, t1 - t0, omp_get_max_threads());
     Out o(outPath);
     o.raw(hits.data(), n * sizeof(HitRec));
 }

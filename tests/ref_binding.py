@@ -132,15 +132,21 @@ def _rays_file(d, origins, directions):
     return path, len(o)
 
 
-def intersect(scene, origins, directions, tri_itemsize=100, use_bvh=True):
+def intersect(scene, origins, directions, tri_itemsize=100, use_bvh=True, timing=None):
     """Closest hits through the reference's boxIntersectionTest / sphereIntersectionTest /
-    meshIntersectionTestBVH (BVHs from the reference's BVH::build) for a scene of this repository."""
+    meshIntersectionTestBVH (BVHs from the reference's BVH::build) for a scene of this repository.
+    timing: a dict that receives rays / seconds / threads of the closest-hit loop alone."""
     desc = scene.desc if hasattr(scene, "desc") else scene
     with tempfile.TemporaryDirectory() as d:
         dp, out = os.path.join(d, "desc.bin"), os.path.join(d, "hits.bin")
         open(dp, "wb").write(_desc_bytes(desc, tri_itemsize))
         rp, n = _rays_file(d, origins, directions)
-        _run(*(["isect", dp, rp, out] + ([] if use_bvh else ["nobvh"])))
+        log = _run(*(["isect", dp, rp, out] + ([] if use_bvh else ["nobvh"])))
+        if timing is not None:
+            for line in log.splitlines():
+                if line.startswith("ref_tool isect:"):
+                    w = line.split()
+                    timing.update(rays=int(w[2]), seconds=float(w[5]), threads=int(w[8]))
         return np.fromfile(out, REF_HIT_DTYPE, n)
 
 
