@@ -256,10 +256,10 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 if (COUNT && tv.best >= 0) cnt.meshHits++;
                 bool blocked = false;
                 if (MODE == TRACE_CLOSEST) {
-                    if (closer(t, gi, best)) {
-                        t = travFinish(S, g, r, tv, true, nn, uv, mat, tri);
-                        best.t = t; best.n = nn; best.mat = mat; best.uv = uv; best.geom = gi; best.tri = tri;
-                    }
+                    /* only what decides the closest hit is kept here: distance, barycentrics, triangle, geom.  Normal,
+                     * uv and material are interpolated by k_prims, one thread per slot with every lane busy, instead of
+                     * here with the few lanes of a refill pass */
+                    if (closer(t, gi, best)) { best.t = t; best.geom = gi; best.tri = tv.best; best.uv.x = tv.bary.y; best.uv.y = tv.bary.z; }
                 } else {
                     blocked = shLight >= 0 ? blocksLight(t, shDist) : blocksEnv(t);
                 }
@@ -271,11 +271,8 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     trav = true;
                     fetch = false;
                 } else if (MODE == TRACE_CLOSEST) {
-                    st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
-                    if (best.t > 0.0f || !S.leanHits) {    /* the same test the readers apply */
-                        st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
-                        st.hitTri[pix] = best.tri;
-                    }
+                    st.hitA[pix] = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(best.tri));
+                    if (best.t > 0.0f) st.hitTri[pix] = best.geom;
                 } else {
                     /* settle the path colour, then the image add the shade stage held back */
                     float4 c = st.col[pix];
@@ -401,23 +398,24 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
             float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix];
             Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
             Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
-            if (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0) {      /* the ray was filed for traversal */
+            const bool traced = S.numBvhMeshes > 0 && __float_as_int(d.w) != 0;      /* the ray was filed for traversal */
+            if (traced) {
+                /* the traversal left (distance, barycentric u, v, leaf-order triangle) and the geom: finish the hit */
                 float4 ha = st.hitA[pix];
-                best.t = ha.x; best.n = f3(ha.y, ha.z, ha.w);
-                if (ha.x > 0.0f || !S.leanHits) {       /* the rest of a miss record is what best already holds */
-                    float4 hb = st.hitB[pix];
-                    best.mat = __float_as_int(hb.x); best.uv.x = hb.y; best.uv.y = hb.z; best.geom = __float_as_int(hb.w);
-                    best.tri = st.hitTri[pix];
+                if (ha.x > 0.0f) {
+                    const int geom = st.hitTri[pix];
+                    best.t = ha.x; best.geom = geom;
+                    meshHitAttributes(S, S.geoms[geom], r.d, __float_as_int(ha.w), ha.y, ha.z, best.n, best.uv, best.mat, best.tri);
                 }
             }
-            const bool traced = best.geom >= 0 || (S.numBvhMeshes > 0 && __float_as_int(d.w) != 0);
-            const int meshGeom = best.geom;
             foldInlineGeoms<COUNT>(S, r, best, cnt);
-            /* the traversal's record stands unless an inline geom is closer; with the sort on, a miss needs no record
-             * at all: the shade stage knows the misses by their place in the sorted order */
-            if ((!traced || best.geom != meshGeom) && !(sortOn && !(best.t > 0.0f))) {
+            /* a hit always gets its full record here; a miss is fully described by its distance (-1), which the
+             * traversal has already stored for a ray it was handed; with the sort on, a miss needs no record at all:
+             * the shade stage knows the misses by their place in the sorted order */
+            const bool hit = best.t > 0.0f;
+            if (hit || !S.leanHits || (!traced && !sortOn)) {
                 st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
-                if (best.t > 0.0f || !S.leanHits) {
+                if (hit || !S.leanHits) {
                     st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
                     st.hitTri[pix] = best.tri;
                 }

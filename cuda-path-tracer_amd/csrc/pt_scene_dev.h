@@ -9,6 +9,8 @@
  *                  col  = (throughput.rgb, remainingBounces as int bits)
  *                and two 16-byte hit records
  *                  hitA = (t, normal.xyz)     hitB = (materialId bits, u, v, geom bits)
+ *                (between the closest-hit traversal and the primitive stage a mesh hit is the lean record
+ *                  hitA = (t, bary u, bary v, leaf-order triangle bits), hitTri = geom)
  *                The wavefront queue holds 4-byte pixel indices only; sorting by
  *                material and compaction permute that queue, never the 80 bytes of
  *                state.  A queue slot index plays the role of the array index the
@@ -453,28 +455,36 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
     return false;
 }
 
+/* Attributes of a mesh hit (second half of the hit epilogue, src/intersections.cu:388-419): interpolated and
+ * transformed normal facing the ray, uv, material and original triangle index of leaf-order triangle `best` hit at
+ * barycentrics (1 - u - v, u, v).  The closest-hit traversal only records (distance, u, v, best, geom); the
+ * one-thread-per-slot stage that follows calls this, with every lane busy, for the hits that survive. */
+PT_DEV void meshHitAttributes(const SceneView& S, const DGeom& g, F3 rayD, int best, float bu, float bv,
+                              F3& N, F2& uv, int& mat, int& triOrig)
+{
+    const float bw = 1.0f - bu - bv;            /* as the triangle test forms it */
+    const float4* cold = S.triCold + 4 * (size_t)(g.triStart + best);
+    float4 c0 = cold[0], c1 = cold[1], c2 = cold[2], c3 = cold[3];
+    F3 n0 = f3(c0.x, c0.y, c0.z), n1 = f3(c0.w, c1.x, c1.y), n2 = f3(c1.z, c1.w, c2.x);
+    F3 ln = normalize(bw * n0 + bu * n1 + bv * n2);
+    uv.x = (bw * c2.y + bu * c2.w) + bv * c3.y;
+    uv.y = (bw * c2.z + bu * c3.x) + bv * c3.z;
+    mat = __float_as_int(c3.w);
+    triOrig = __float_as_int(S.triHot[3 * ((size_t)g.triStart + (size_t)best) + 2].y);
+    N = normalize(mulMV(g.IT, ln, 0.0f));
+    bool outside = dot(rayD, N) < 0.0f;
+    if (!outside) N = -N;
+}
+
 /* hit epilogue (src/intersections.cu:388-419): world distance, and when wantAttr the interpolated
  * normal / uv / material of the best triangle */
 PT_DEV float travFinish(const SceneView& S, const DGeom& g, const Ray& r, const MeshTrav& tv, bool wantAttr,
                         F3& N, F2& uv, int& mat, int& triOrig)
 {
     if (tv.best < 0) return -1.0f;
-    const float4* hot = S.triHot + 3 * (size_t)g.triStart;
     F3 localP = tv.lo + tv.ld * tv.closestT;
     F3 P = mulMV(g.T, localP, 1.0f);
-    if (wantAttr) {
-        const float4* cold = S.triCold + 4 * (size_t)(g.triStart + tv.best);
-        float4 c0 = cold[0], c1 = cold[1], c2 = cold[2], c3 = cold[3];
-        F3 n0 = f3(c0.x, c0.y, c0.z), n1 = f3(c0.w, c1.x, c1.y), n2 = f3(c1.z, c1.w, c2.x);
-        F3 ln = normalize(tv.bary.x * n0 + tv.bary.y * n1 + tv.bary.z * n2);
-        uv.x = (tv.bary.x * c2.y + tv.bary.y * c2.w) + tv.bary.z * c3.y;
-        uv.y = (tv.bary.x * c2.z + tv.bary.y * c3.x) + tv.bary.z * c3.z;
-        mat = __float_as_int(c3.w);
-        triOrig = __float_as_int(hot[3 * (size_t)tv.best + 2].y);
-        N = normalize(mulMV(g.IT, ln, 0.0f));
-        bool outside = dot(r.d, N) < 0.0f;
-        if (!outside) N = -N;
-    }
+    if (wantAttr) meshHitAttributes(S, g, r.d, tv.best, tv.bary.y, tv.bary.z, N, uv, mat, triOrig);
     return length(r.o - P);
 }
 
