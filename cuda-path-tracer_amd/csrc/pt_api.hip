@@ -25,7 +25,7 @@ void pt_set_error(const char* fmt, ...);
 void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount);
 void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount);
 void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
-               uint32_t* fetchCtr, const uint32_t* workCount, void* dc);
+               uint32_t* fetchCtr, const uint32_t* workCount, void* dc, int share = 1);
 void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc, bool sparse);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
@@ -92,6 +92,16 @@ struct PtContext {
     hipStream_t shadowStreams[kMaxStreamGroups] = {};
     hipEvent_t shadedEvents[kMaxStreamGroups] = {}, shadowDoneEvents[kMaxStreamGroups] = {};
     int shadowOverlap = 1;
+    /* One-iteration calls (pt_trace) rotate over `pipeDepth` rows of the path state, each with streams of its own:
+     * the traversal kernels of one iteration spend most of their time draining a few long rays, and the next calls'
+     * kernels fill the machine meanwhile.  Every call's accumulation into the image runs on the main stream in call
+     * order, so the image is the same as with one call at a time. */
+    int pipeDepth = 4;
+    unsigned pipeNext = 0;
+    int pipeLast = -1;
+    bool pipeBarrier = false;           /* work on the main stream has used the path state since the last pipelined call */
+    bool slotBusy[kMaxStreamGroups] = {};
+    hipEvent_t slotFreeEvents[kMaxStreamGroups] = {};
     /* Live-path maxima per bounce of the last finished launch group, copied to pinned memory behind every group.
      * They only choose the launch form of the heavy per-slot kernels for the next group (nearly empty bounces take
      * the bounded grid); either form is correct for any count. */
@@ -869,6 +879,7 @@ int pt_destroy(PtContext* c)
         if (c->shadowStreams[g]) (void)hipStreamDestroy(c->shadowStreams[g]);
         if (c->shadedEvents[g]) (void)hipEventDestroy(c->shadedEvents[g]);
         if (c->shadowDoneEvents[g]) (void)hipEventDestroy(c->shadowDoneEvents[g]);
+        if (c->slotFreeEvents[g]) (void)hipEventDestroy(c->slotFreeEvents[g]);
     }
     if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
     if (c->hintEvent) (void)hipEventDestroy(c->hintEvent);
@@ -930,7 +941,9 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
         TRY_HIP(hipStreamCreateWithFlags(&c->shadowStreams[g], hipStreamNonBlocking));
         TRY_HIP(hipEventCreateWithFlags(&c->shadedEvents[g], hipEventDisableTiming));
         TRY_HIP(hipEventCreateWithFlags(&c->shadowDoneEvents[g], hipEventDisableTiming));
+        TRY_HIP(hipEventCreateWithFlags(&c->slotFreeEvents[g], hipEventDisableTiming));
     }
+    { const char* e = getenv("PT_PIPELINE"); if (e) c->pipeDepth = std::max(1, std::min(atoi(e), kMaxStreamGroups)); }
     { const char* e = getenv("PT_SHADOW_OVERLAP"); if (e) c->shadowOverlap = atoi(e) != 0; }
     { const char* e = getenv("PT_ROWS_PER_GROUP"); if (e && atoi(e) > 0) c->rowsPerGroup = atoi(e); }
     { const char* e = getenv("PT_STREAMS"); int v = e ? atoi(e) : kDefaultStreamGroups; c->streamGroups = std::max(1, std::min(v, kMaxStreamGroups)); c->streamsFixed = e != nullptr; }
@@ -1086,12 +1099,41 @@ static int traceBatch(PtContext* c, Batch bt)
     memcpy(V.camPos, c->cam.position, sizeof(V.camPos));
     const bool count = c->counters != 0;
     uint32_t* ctr = c->workCtr;
-    HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
+    const bool meshes = V.numBvhMeshes > 0;
+    /* a one-iteration call takes the next of `pipe` path-state rows and that row's streams; see PtContext::pipeDepth */
+    const int pipe = std::min(std::min(c->pipeDepth, c->batch), kMaxStreamGroups);
+    const bool piped = bt.count == 1 && pipe > 1 && !c->timing && meshes;
+    const int slot = piped ? (int)(c->pipeNext++ % (unsigned)pipe) : 0;
+    /* Is the caller issuing calls ahead of the device?  Then up to `pipe` iterations are in flight: each traversal launch
+     * takes 1/pipe of the machine's workgroup slots so that they run side by side (as the rows of a launch group do), and
+     * the shadow traversal stays on the row's one stream (more streams than hardware queues get in each other's way).
+     * A caller that waits after every call finds the previous row idle and gets the whole machine per launch. */
+    bool ahead = false;
+    if (piped && c->pipeLast >= 0 && c->slotBusy[c->pipeLast]) ahead = hipEventQuery(c->slotFreeEvents[c->pipeLast]) == hipErrorNotReady;
+    static const int shareEnv = [] { const char* e = getenv("PT_PIPE_SHARE"); return e ? atoi(e) : 0; }();
+    const int share = !piped ? 1 : shareEnv > 0 ? shareEnv : ahead ? pipe : 1;
+    if (piped) c->pipeLast = slot;
+    if (piped) {
+        if (c->pipeBarrier) {
+            /* other work on the main stream has used the path state or the counters since: every row waits for it once */
+            HIP_TRY(hipEventRecord(c->forkEvent, s));
+            for (int g = 0; g < pipe; ++g) HIP_TRY(hipStreamWaitEvent(c->groupStreams[g], c->forkEvent, 0));
+            c->pipeBarrier = false;
+        }
+        /* the row is free again once the accumulation of the call that used it last has read it */
+        if (c->slotBusy[slot]) HIP_TRY(hipStreamWaitEvent(c->groupStreams[slot], c->slotFreeEvents[slot], 0));
+        /* this row's counter lines only (one line per section and bounce, kMaxBatch lines apart) */
+        HIP_TRY(hipMemset2DAsync(ctr + (size_t)slot * kCtrStride, (size_t)kMaxBatch * kCtrStride * sizeof(uint32_t), 0, kCtrStride * sizeof(uint32_t),
+                                 (size_t)kWorkCtrCount / ((size_t)kMaxBatch * kCtrStride), c->groupStreams[slot]));
+    } else {
+        /* the main stream has been made to wait for every pipelined call when that call was issued */
+        HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
+        c->pipeBarrier = true;
+    }
     uint32_t* closestFetch = ctr;
     uint32_t* shadowFetch = ctr + kWorkCtrSection;
     uint32_t* shadowCount = ctr + 2 * kWorkCtrSection;
     uint32_t* closestCount = ctr + 3 * kWorkCtrSection;
-    const bool meshes = V.numBvhMeshes > 0;
     if (c->hintPending && hipEventQuery(c->hintEvent) == hipSuccess) {
         memcpy(c->liveHint, c->liveHintHost, sizeof(c->liveHint));
         c->hintPending = false;
@@ -1125,10 +1167,11 @@ static int traceBatch(PtContext* c, Batch bt)
     if (tuning) HIP_TRY(hipEventRecord(c->tuneStart, s));
     if (groups > 1) HIP_TRY(hipEventRecord(c->forkEvent, s));
     for (int g = 0; g < groups; ++g) {
-        const int r0 = (int)((long long)bt.count * g / groups), r1 = (int)((long long)bt.count * (g + 1) / groups);
-        hipStream_t gs = groups > 1 ? c->groupStreams[g] : s;
+        const int r0 = piped ? slot : (int)((long long)bt.count * g / groups), r1 = piped ? slot + 1 : (int)((long long)bt.count * (g + 1) / groups);
+        const int sx = piped ? slot : g;        /* which streams and events */
+        hipStream_t gs = (piped || groups > 1) ? c->groupStreams[sx] : s;
         if (groups > 1) HIP_TRY(hipStreamWaitEvent(gs, c->forkEvent, 0));
-        Batch gb; gb.count = r1 - r0; gb.iterBase = bt.iterBase + r0 * bt.iterStride; gb.iterStride = bt.iterStride;
+        Batch gb; gb.count = r1 - r0; gb.iterBase = bt.iterBase + (piped ? 0 : r0 * bt.iterStride); gb.iterStride = bt.iterStride;
         PathState st = c->state.at(r0);
         Queues q = c->queues.at(r0);
         const size_t rowOff = (size_t)r0 * kCtrStride;
@@ -1137,8 +1180,8 @@ static int traceBatch(PtContext* c, Batch bt)
          * stage and the sort do not look at either.  It therefore runs on a side stream next to them and is
          * joined before the next shade stage (or the final gather) reads colours again: one more kernel whose
          * tail of long rays is covered by other work. */
-        const bool side = meshes && !c->timing && c->shadowOverlap && groups == 1 && !inlineShadow;     /* more streams than three get in each other's way */
-        hipStream_t ss = side ? c->shadowStreams[g] : gs;
+        const bool side = meshes && !c->timing && c->shadowOverlap && groups == 1 && !inlineShadow && share == 1;     /* more streams than three get in each other's way */
+        hipStream_t ss = side ? c->shadowStreams[sx] : gs;
         bool shadowOpen = false;
         for (int b = 0; b < c->traceDepth; ++b) {
             const size_t row = (size_t)b * kMaxBatch * kCtrStride + rowOff;
@@ -1146,32 +1189,34 @@ static int traceBatch(PtContext* c, Batch bt)
                 SpanGuard sg(c, ST_INTERSECT, gs);
                 if (meshes) {
                     SpanGuard t(c, ST_TRACE, gs);
-                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + row, closestCount + row, c->dc);
+                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + row, closestCount + row, c->dc, share);
                 }
                 ptl_prims(gs, V, st, q, gb, b, c->sortOn, count, c->dc, sparseBounce(b));
             }
             if (c->sortOn) { SpanGuard sg(c, ST_SORT, gs); ptl_sort(gs, q, gb, b, V.numBuckets); }
             {
-                if (shadowOpen) { HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[g], 0)); shadowOpen = false; }
+                if (shadowOpen) { HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[sx], 0)); shadowOpen = false; }
                 SpanGuard sg(c, ST_SHADE, gs);
                 ptl_shade(gs, V, st, q, gb, b, c->sortOn, count, shadowCount + row,
                           (meshes && b + 1 < c->traceDepth) ? closestCount + row + (size_t)kMaxBatch * kCtrStride : nullptr, c->dc, sparseBounce(b));
                 if (meshes) {
-                    if (side) { HIP_TRY(hipEventRecord(c->shadedEvents[g], gs)); HIP_TRY(hipStreamWaitEvent(ss, c->shadedEvents[g], 0)); }
+                    if (side) { HIP_TRY(hipEventRecord(c->shadedEvents[sx], gs)); HIP_TRY(hipStreamWaitEvent(ss, c->shadedEvents[sx], 0)); }
                     SpanGuard t(c, ST_SHADOW_TRACE, ss);
-                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc);
-                    if (side) { HIP_TRY(hipEventRecord(c->shadowDoneEvents[g], ss)); shadowOpen = true; }
+                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc, share);
+                    if (side) { HIP_TRY(hipEventRecord(c->shadowDoneEvents[sx], ss)); shadowOpen = true; }
                 }
             }
             { SpanGuard sg(c, ST_COMPACT, gs); ptl_compact(gs, q, gb, b, c->sortOn); }
         }
-        if (shadowOpen) HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[g], 0));
-        if (groups > 1) {
-            HIP_TRY(hipEventRecord(c->joinEvents[g], gs));
-            HIP_TRY(hipStreamWaitEvent(s, c->joinEvents[g], 0));
+        if (shadowOpen) HIP_TRY(hipStreamWaitEvent(gs, c->shadowDoneEvents[sx], 0));
+        if (piped || groups > 1) {
+            HIP_TRY(hipEventRecord(c->joinEvents[sx], gs));
+            HIP_TRY(hipStreamWaitEvent(s, c->joinEvents[sx], 0));
         }
     }
-    ptl_finish(s, c->state, c->queues, bt, c->traceDepth, c->imageSum, c->dc, shadowCount, closestCount, kMaxBatch);
+    ptl_finish(s, c->state.at(slot), c->queues.at(slot), bt, c->traceDepth, c->imageSum, c->dc, shadowCount + (size_t)slot * kCtrStride,
+               closestCount + (size_t)slot * kCtrStride, kMaxBatch);
+    if (piped) { HIP_TRY(hipEventRecord(c->slotFreeEvents[slot], s)); c->slotBusy[slot] = true; }
     if (tuning) {
         HIP_TRY(hipEventRecord(c->tuneEnd, s));
         HIP_TRY(hipEventSynchronize(c->tuneEnd));
@@ -1326,7 +1371,15 @@ int pt_stats(PtContext* c, PtStats* out)
     if (getenv("PT_DEBUG_TAIL"))
         for (int m = 0; m < 2; ++m)
             fprintf(stderr, "[pt] traversal mode %d: wave iterations %llu, node lanes %llu, leaf lanes %llu, held leaf lanes %llu, refills %llu, refilled lanes %llu\n", m,
-                    h.waveDiag[m][0], h.waveDiag[m][1], h.waveDiag[m][2], h.waveDiag[m][3], h.waveDiag[m][4], h.waveDiag[m][5]);
+                    h.waveDiag[m][0], h.waveDiag[m][1], h.waveDiag[m][2], h.waveDiag[m][3], h.waveDiag[m][4], h.waveDiag[m][5]),
+            fprintf(stderr, "[pt] traversal mode %d: longest wave %u iterations\n", m, h.maxWaveIters[m]);
+    if (getenv("PT_DEBUG_TAIL")) {
+        fprintf(stderr, "[pt] waves ending per 25 us slot:");
+        for (int i = 0; i < 64; ++i) fprintf(stderr, " %u", h.finishHist[i]);
+        fprintf(stderr, "\n[pt] waves seeing the queue dry per 25 us slot:");
+        for (int i = 0; i < 64; ++i) fprintf(stderr, " %u", h.dryHist[i]);
+        fprintf(stderr, "\n");
+    }
     out->shadeNodesVisited = h.trav[1][0]; out->shadeTrisTested = h.trav[1][1]; out->shadeMeshHits = h.trav[1][2];
     out->msCamera = c->ms[ST_CAMERA]; out->msIntersect = c->ms[ST_INTERSECT]; out->msSort = c->ms[ST_SORT];
     out->msShade = c->ms[ST_SHADE]; out->msCompact = c->ms[ST_COMPACT];
@@ -1374,6 +1427,7 @@ static int intersectStaged(PtContext* c, const float* origins, const float* dire
         if (e == hipSuccess) e = hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) {
             Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
+            c->pipeBarrier = true;      /* row 0 of the path state is used on the main stream */
             ptl_import_rays(c->stream, c->state, c->queues, dO, dD, m);
             if (V.numBvhMeshes > 0) {
                 { MaybeSpan g(c, ST_INTERSECT, spans); ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection); }
@@ -1442,6 +1496,7 @@ int pt_capture_gbuffer(PtContext* c, int iter, float* normals, float* albedo)
     Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
     HIP_TRY(hipMemsetAsync(ctr, 0, kCtrStride * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream));
+    c->pipeBarrier = true;      /* row 0 of the path state is used on the main stream */
     ptl_camera(c->stream, V, c->cam, bt, c->traceDepth, c->state, c->queues, V.numBvhMeshes > 0 ? ctr + 3 * kWorkCtrSection : nullptr);
     if (V.numBvhMeshes > 0) ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, ctr, ctr + 3 * kWorkCtrSection, nullptr);
     ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr, false);
@@ -1492,6 +1547,7 @@ int pt_camera_rays(PtContext* c, int iter, float* origins, float* directions)
     Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
     SceneView V = c->view;
     V.numBvhMeshes = 0;          /* no work list wanted here */
+    c->pipeBarrier = true;      /* row 0 of the path state is used on the main stream */
     ptl_camera(c->stream, V, c->cam, bt, c->traceDepth, c->state, c->queues, nullptr);
     ptl_export_rays(c->stream, c->state, n, dO, dD);
     hipError_t e = hipGetLastError();

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #define PT_REFILL 24
 #endif
 #ifndef PT_TRACE_MINWAVES
-#define PT_TRACE_MINWAVES 4
+#define PT_TRACE_MINWAVES 5
 #endif
 #ifndef PT_SHADE_MINWAVES
 #define PT_SHADE_MINWAVES 5
@@ -241,6 +241,11 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     travInit(S.geoms[firstMesh], r, tv);
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tStart = 0, tDry = 0;
+    if (COUNT && MODE == TRACE_CLOSEST) {
+        tStart = wall_clock64();
+        if (lane == 0) atomicCAS(&dc->launchT0, 0ull, tStart);
+    }
 
     /* every wave leaves this loop: a lane's walk ends when its stack is empty, a wave stops fetching once all
      * eight pieces have been seen dry, and then breaks out as soon as no lane is walking */
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                         const int dist = (k - seg) & (kSegments - 1);
                         if (cur < len && dist < foundDist) foundDist = dist;
                     }
-                    if (foundDist == kSegments) { segsLeft = 0; if (fetch) exhausted = true; break; }
+                    if (foundDist == kSegments) { segsLeft = 0; if (COUNT) tDry = wall_clock64(); if (fetch) exhausted = true; break; }
                     seg = (seg + foundDist) & (kSegments - 1);
                 }
                 const uint32_t segBegin = (uint32_t)(((unsigned long long)n * (unsigned)seg) / kSegments);
@@ -364,8 +369,17 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     }
     if (COUNT) {
         flushCounters(cnt, dc, MODE);
-        if (lane == 0)
+        if (lane == 0) {
             for (int i = 0; i < 6; ++i) atomicAdd(&dc->waveDiag[MODE][i], diag[i]);
+            atomicMax(&dc->maxWaveIters[MODE], (unsigned)diag[0]);
+            if (MODE == TRACE_CLOSEST) {
+                const unsigned long long t0 = __hip_atomic_load(&dc->launchT0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long te = wall_clock64();
+                unsigned b = (unsigned)((te - t0) / 2500ull); if (b > 63u) b = 63u;
+                atomicAdd(&dc->finishHist[b], 1u);
+                if (tDry) { unsigned d = (unsigned)((tDry - t0) / 2500ull); if (d > 63u) d = 63u; atomicAdd(&dc->dryHist[d], 1u); }
+            }
+        }
     }
 }
 
@@ -879,9 +893,10 @@ void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch b
     hipLaunchKernelGGL(k_cull, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, workCount);
 }
 void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
-               uint32_t* fetchCtr, const uint32_t* workCount, void* dc)
+               uint32_t* fetchCtr, const uint32_t* workCount, void* dc, int share)
 {
-    dim3 grid(persistentGridX(bt.count), bt.count);
+    /* share: launches expected to run side by side with this one (they split the machine's workgroup slots) */
+    dim3 grid(persistentGridX(bt.count * (share > 1 ? share : 1)), bt.count);
     DevCounters* d = (DevCounters*)dc;
     if (shadow) {
         if (count) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);

@@ -157,6 +157,9 @@ struct DevCounters {
     unsigned long long workItems[2];    /* rays handed to the traversal kernel: closest-hit, shadow */
     unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
     unsigned maxStack[2];               /* deepest traversal stack any ray reached, per stage (entries; beyond kLdsStack they live in private memory) */
+    unsigned maxWaveIters[2];           /* most loop iterations any wave of a traversal launch made (the launch's critical path) */
+    unsigned long long launchT0;        /* diagnostics: wall clock of the first wave of the traversal launch being looked at */
+    unsigned finishHist[64], dryHist[64];   /* waves by the 25 us slot they ended in / first saw the queue dry in */
     unsigned long long waveDiag[2][6];  /* per traversal mode: wave iterations, node-step lanes, leaf-step lanes, held-leaf lanes, refills, refilled lanes */
     uint32_t lastLive[PT_MAX_DEPTH + 2];
     uint32_t liveMax[PT_MAX_DEPTH + 2]; /* per bounce, the largest live count over the rows of the last launch group */

@@ -271,6 +271,48 @@ def test_batched_iterations_bit_exact(pt, scenes, orc, gpu_ok):
     assert _same_bits(tr.image(), o.image())
 
 
+def test_one_iteration_calls_in_flight_bit_exact(pt, scenes, orc, gpu_ok):
+    """pt_trace calls issued without waiting rotate over rows of the path state with streams of their own and overlap on
+    the device; their sums must equal the one-at-a-time result, also with a wait after every call, with stage-level calls
+    (which use row 0 on the main stream) in between, and with pt_clear / pt_display between calls."""
+    sc = scenes.make_scene("dragon", res=(96, 64), depth=8, grid=(48, 49), env_size=(64, 32), tex_size=16)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    sums = {}
+    for it in range(1, 30):
+        o.trace(it)
+        sums[it] = o.image().copy()
+    tr = pt.Tracer(sc)
+    for it in range(1, 30):
+        tr.trace(it)                            # no wait: up to four iterations in flight
+    assert _same_bits(tr.image(), sums[29])
+    assert tr.stats().pathBounces == o.stats().pathBounces
+    assert list(tr.stats().lastLive[:9]) == list(o.stats().lastLive[:9])
+    tr = pt.Tracer(sc)
+    for it in range(1, 12):
+        tr.trace(it)
+        tr.sync()                               # a caller that waits every time
+    assert _same_bits(tr.image(), sums[11])
+    tr = pt.Tracer(sc)
+    ro, rd = _ray_set(9, 5000, center=(0.0, 4.0, 0.0), radius=9.0)
+    want_hits = o.intersect(ro, rd)
+    for it in range(1, 12):
+        tr.trace(it)
+        if it in (3, 4, 9):
+            _hits_equal(tr.intersect(ro, rd), want_hits)
+        if it == 6:
+            tr.capture_gbuffer(1)
+        if it == 7:
+            tr.camera_rays(2)
+    assert _same_bits(tr.image(), sums[11])
+    # launch groups and single calls mixed
+    tr = pt.Tracer(sc)
+    tr.trace(1); tr.trace(2); tr.trace(3)
+    tr.set_option(pt.PT_OPT_BATCH, 4)
+    tr.trace_range(4, 10)
+    tr.trace(10); tr.trace(11)
+    assert _same_bits(tr.image(), sums[11])
+
+
 def test_launch_shapes_and_largest_groups_bit_exact(pt, scenes, orc, gpu_ok):
     """Groups of 12 iterations or more go through the library's launch-shape trial (one, two, three streams, one stream
     with the shadow traversal in line, then the kept shape), and a group may hold up to 512 iterations: the sum is

@@ -1,4 +1,5 @@
-"""One iteration per call (the reference-shaped use of the loop): python tools/diag/single_iter.py [workload] [iterations]"""
+"""One iteration per call (the reference-shaped use of the loop): python tools/diag/single_iter.py [workload] [iterations]
+SYNC_EACH=1 waits for the device after every call."""
 import importlib
 import os
 import sys
@@ -15,7 +16,6 @@ name = sys.argv[1] if len(sys.argv) > 1 else "dragon"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 scene_name, res, depth, _ = bench.WORKLOADS[name]
 sc = bench.make_workload_scene(scenes, pt, scene_name, res, depth, 0)
-os.environ.setdefault("PT_BATCH", "1")
 tr = pt.Tracer(sc)
 for it in range(1, 4):
     tr.trace(it)
@@ -24,6 +24,8 @@ tr.reset_stats()
 t0 = time.perf_counter()
 for it in range(4, 4 + iters):
     tr.trace(it)
+    if os.environ.get("SYNC_EACH"):
+        tr.sync()
 tr.sync()
 t1 = time.perf_counter()
 st = tr.stats()
