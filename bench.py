@@ -359,10 +359,18 @@ def main():
             tr.sync()
             s1 = time.perf_counter()
             ss = tr.stats()
+            w0 = time.perf_counter()
+            for it in range(2 + n_single, 2 + n_single + 16):
+                tr.trace(it)
+                tr.sync()
+            w1 = time.perf_counter()
             extras["single_iteration"] = {"ms_per_iter": round((s1 - s0) / n_single * 1e3, 4),
                                           "Mpaths_bounce_s": round(ss.pathBounces / (s1 - s0) / 1e6, 1), "iterations": n_single,
-                                          "path_state_bytes_in_flight": int(176 * npix),
-                                          "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end"}
+                                          "ms_per_iter_waiting_after_every_call": round((w1 - w0) / 16 * 1e3, 4),
+                                          "path_state_bytes_in_flight": int(176 * npix) * 4,
+                                          "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end: up to four calls "
+                                                 "overlap on the device (a row of the path state and a stream each, accumulation in call order); "
+                                                 "the second figure has a host wait after every call, nothing overlaps"}
             extras["path_state_bytes_in_flight"] = int(176 * npix) * B
             if st.launchesTrace > 0:
                 extras["ray_sets"] = _ray_sets(pt, tr, npix)

@@ -347,15 +347,29 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
                 cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
                              (__float_as_int(rf.z) != kEmptyRef) + (__float_as_int(rf.w) != kEmptyRef);
             }
-#define PT_CHILD_FAST(k, C)                                                                         \
+            /* plane distances two children at a time: gfx950 has packed single-precision add and multiply (two IEEE
+             * operations per instruction, same results as the scalar forms), which halves the 48 instructions of the
+             * 24 slab distances */
+            typedef float pk2 __attribute__((ext_vector_type(2)));
+            const pk2 ox = { lo.x, lo.x }, oy = { lo.y, lo.y }, oz = { lo.z, lo.z };
+            const pk2 ix = { invDir.x, invDir.x }, iy = { invDir.y, invDir.y }, iz = { invDir.z, invDir.z };
+#define PT_PAIR(P, a, b) (pk2){ P.a, P.b }
+            const pk2 nx0 = (PT_PAIR(nX, x, y) - ox) * ix, nx1 = (PT_PAIR(nX, z, w) - ox) * ix;
+            const pk2 ny0 = (PT_PAIR(nY, x, y) - oy) * iy, ny1 = (PT_PAIR(nY, z, w) - oy) * iy;
+            const pk2 nz0 = (PT_PAIR(nZ, x, y) - oz) * iz, nz1 = (PT_PAIR(nZ, z, w) - oz) * iz;
+            const pk2 fx0 = (PT_PAIR(fX, x, y) - ox) * ix, fx1 = (PT_PAIR(fX, z, w) - ox) * ix;
+            const pk2 fy0 = (PT_PAIR(fY, x, y) - oy) * iy, fy1 = (PT_PAIR(fY, z, w) - oy) * iy;
+            const pk2 fz0 = (PT_PAIR(fZ, x, y) - oz) * iz, fz1 = (PT_PAIR(fZ, z, w) - oz) * iz;
+#undef PT_PAIR
+#define PT_CHILD_FAST(k, H, E, C)                                                                   \
             {                                                                                        \
-                float tMin = __builtin_fmaxf(__builtin_fmaxf((nX.C - lo.x) * invDir.x, (nY.C - lo.y) * invDir.y), (nZ.C - lo.z) * invDir.z); \
-                float tMax = __builtin_fminf(__builtin_fminf((fX.C - lo.x) * invDir.x, (fY.C - lo.y) * invDir.y), (fZ.C - lo.z) * invDir.z); \
+                float tMin = __builtin_fmaxf(__builtin_fmaxf(nx##H.E, ny##H.E), nz##H.E);             \
+                float tMax = __builtin_fminf(__builtin_fminf(fx##H.E, fy##H.E), fz##H.E);             \
                 bool in = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);                      \
                 tk[k] = in ? tMin : INF;                                                             \
                 rk[k] = __float_as_int(rf.C);                                                        \
             }
-            PT_CHILD_FAST(0, x) PT_CHILD_FAST(1, y) PT_CHILD_FAST(2, z) PT_CHILD_FAST(3, w)
+            PT_CHILD_FAST(0, 0, x, x) PT_CHILD_FAST(1, 0, y, y) PT_CHILD_FAST(2, 1, x, z) PT_CHILD_FAST(3, 1, y, w)
 #undef PT_CHILD_FAST
         } else {
             const float4* q = S.nodes + 8 * ((size_t)tv.nodeStart + (size_t)ref);

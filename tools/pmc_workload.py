@@ -15,6 +15,8 @@ one stream (steps x depth launches of each traversal kernel).  Counter arithmeti
   lane instructions  = SQ_INSTS_VALU x 64 x lane utilisation
   HBM bytes          = (2 x FETCH_SIZE + WRITE_SIZE) x 1024   (FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950)
   L2 hit rate        = TCC_HIT / (TCC_HIT + TCC_MISS)
+  L1 tag pipe        = TCP_TOTAL_CACHE_ACCESSES / (256 CUs x cycles): the vector L1 looks up one line per cycle; a 16-byte-per-lane
+                       load of a full wave costs at least 16 lookups however few lines it touches
 """
 import csv
 import glob
@@ -100,6 +102,18 @@ def main():
         e["l2_hit_rate"] = round(hit / (hit + miss), 4) if hit + miss else None
         e["l2_requests"] = l2.get("TCC_REQ_sum")
         e["ta_busy_avr"] = round(l2.get("TA_BUSY_avr", 0.0) / max(l2["_launches"], 1), 2) if l2.get("_launches") else None
+        # vector L1: one tag lookup per cycle and CU; cycles of the l2 pass = its own kernel time x the clock the sq2 pass saw
+        # (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+        clock = sq2.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / sq2["_ns"] * 1e9 if sq2.get("_ns") else 2.4e9
+        l2cyc = l2["_ns"] * 1e-9 * clock if l2.get("_ns") else 0.0
+        lookups = l2.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)
+        e["shader_clock_ghz"] = round(clock / 1e9, 3)
+        e["l1_tag_lookups"] = lookups
+        e["l1_tag_busy"] = round(lookups / 256.0 / l2cyc, 4) if l2cyc else None
+        e["l1_hit_rate"] = round(1.0 - l2.get("TCP_TCC_READ_REQ_sum", 0.0) / lookups, 4) if lookups else None
+        e["ta_busy"] = round(l2.get("TA_BUSY_avr", 0.0) / l2cyc, 4) if l2cyc else None
+        if sq2.get("SQ_INSTS_VMEM_RD"):
+            e["l1_tag_lookups_per_load_instruction"] = round(lookups / sq2["SQ_INSTS_VMEM_RD"], 2)
         hbm = (2.0 * fe.get("FETCH_SIZE", 0.0) + wr.get("WRITE_SIZE", 0.0)) * 1024.0
         e["hbm_bytes"] = round(hbm)
         e["hbm_read_bytes(2xFETCH_SIZE)"] = round(2.0 * fe.get("FETCH_SIZE", 0.0) * 1024.0)
@@ -112,9 +126,9 @@ def main():
             if c in sq2:
                 e[c.lower()] = sq2[c]
         res[k] = e
-        lines.append("%-22s launches %3d  %9.2f ms  VALU issue %5.1f%%  lanes %5.1f%%  VALU share of wave time %5.1f%%  waiting %5.1f%%  L2 hit %5.1f%%  HBM %8.2f GB (%6.1f GB/s)" % (
+        lines.append("%-22s launches %3d  %9.2f ms  VALU issue %5.1f%%  lanes %5.1f%%  VALU share of wave time %5.1f%%  waiting %5.1f%%  L1 tag pipe %5.1f%%  L2 hit %5.1f%%  HBM %8.2f GB (%6.1f GB/s)" % (
             k, e["launches_summed"], e["ms_total_under_counters"], 100 * (e["valu_issue_utilisation"] or 0), 100 * (lane or 0),
-            100 * (e["valu_share_of_wave_time"] or 0), 100 * (e["wait_any_share_of_wave_time"] or 0), 100 * (e["l2_hit_rate"] or 0),
+            100 * (e["valu_share_of_wave_time"] or 0), 100 * (e["wait_any_share_of_wave_time"] or 0), 100 * (e["l1_tag_busy"] or 0), 100 * (e["l2_hit_rate"] or 0),
             hbm / 1e9, e["hbm_gbs_under_counters"] or 0))
     out = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
     json.dump(res, open(out, "w"), indent=1)
