@@ -6,6 +6,7 @@ set -e -o pipefail
 W=${1:-dragon}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/${2:-gpurun_out/prof_$W}
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
