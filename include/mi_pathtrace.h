@@ -229,8 +229,13 @@ int pt_create(const PtSceneDesc* scene, int device, PtContext** out);
 int pt_destroy(PtContext* ctx);
 
 /* pathtrace(pbo = NULL, frame, iter) (src/pathtrace.cu:2659-2930): one sample
- * per pixel, accumulated into the running-sum image.  Asynchronous on the
- * context's stream. */
+ * per pixel, accumulated into the running-sum image.  Asynchronous: the call
+ * returns before the device is done, and calls issued ahead of the device
+ * overlap there (up to four iterations in flight, each on a row of the path
+ * state with streams of its own; environment PT_PIPELINE=1 turns that off).
+ * Their sums reach the image in call order, so it holds the same bits as with
+ * one call at a time; every other entry point that reads the image or uses the
+ * path state is ordered after all calls made before it. */
 int pt_trace(PtContext* ctx, int iter);
 
 /* Sample split: iterations iter_begin, iter_begin+stride, ... < iter_end.  Up to
