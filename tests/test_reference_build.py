@@ -290,7 +290,7 @@ def test_image_writers_equal_the_reference_writers(pt, tmp_path):
 
 
 def test_maintainer_shim_compiles_against_the_reference_headers():
-    """integration/pathtrace_mi355x.cpp (the file INTEGRATION.md tells a maintainer to add) is compiled by oracle/Makefile
+    """integration/pathtrace_mi355x.cpp (the file a maintainer of the reference adds to its build) is compiled by oracle/Makefile
     against the reference's own pathtrace.h / scene.h / sceneStructs.h and linked with the reference's loader and
     libmi_pathtrace.so; what it renders is checked on the GPU (tests/test_gpu_full_size.py)."""
     render = os.path.join(os.path.dirname(ref.TOOL), "ref_render")
