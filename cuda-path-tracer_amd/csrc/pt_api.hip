@@ -63,6 +63,11 @@ constexpr int kTuneMinRows = 12;        /* smaller launch groups stay on one str
  * 3 = closest-hit work queue length */
 constexpr int kWorkCtrSection = (PT_MAX_DEPTH + 1) * kMaxBatch * kCtrStride;      /* one 128-byte line per counter */
 constexpr int kWorkCtrCount = 4 * kWorkCtrSection;
+/* sections 0 and 1 hold one line per (bounce, row) and are no longer used; the fetch counters proper are
+ * [kind: closest, shadow][bounce][segment][row] in PtContext::fetchCtr (see kSegPitch) */
+static_assert(kMaxBatch == kCtrRows, "counter layout");
+constexpr size_t kFetchKind = (size_t)(PT_MAX_DEPTH + 1) * kFetchBouncePitch;
+constexpr size_t kFetchCtrCount = 2 * kFetchKind;
 
 enum Stage { ST_CAMERA = 0, ST_INTERSECT, ST_SORT, ST_SHADE, ST_COMPACT, ST_TRACE, ST_SHADOW_TRACE, ST_COUNT };   /* the last two nest inside intersect / shade */
 
@@ -83,6 +88,7 @@ struct PtContext {
     Queues queues{};
     DevCounters* dc = nullptr;
     uint32_t* workCtr = nullptr;
+    uint32_t* fetchCtr = nullptr;
     void* staging = nullptr;            /* this device's copy of `scratch` */
     int bvhMeshGeoms = 0;               /* mesh geoms that own a BVH */
     int streamGroups = 1;               /* streams the rows of a launch group are spread over */
@@ -1076,6 +1082,8 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
         TRY_RC(allocBatchState(c, batch));
     }
     TRY_RC(devAlloc(c, &c->workCtr, (size_t)kWorkCtrCount));
+    TRY_RC(devAlloc(c, &c->fetchCtr, kFetchCtrCount));
+    TRY_HIP(hipMemset(c->fetchCtr, 0, kFetchCtrCount * sizeof(uint32_t)));
     TRY_RC(devAlloc(c, &c->dc, 1));
     TRY_HIP(hipMemset(c->dc, 0, sizeof(DevCounters)));
     TRY_HIP(hipDeviceSynchronize());
@@ -1125,13 +1133,18 @@ static int traceBatch(PtContext* c, Batch bt)
         /* this row's counter lines only (one line per section and bounce, kMaxBatch lines apart) */
         HIP_TRY(hipMemset2DAsync(ctr + (size_t)slot * kCtrStride, (size_t)kMaxBatch * kCtrStride * sizeof(uint32_t), 0, kCtrStride * sizeof(uint32_t),
                                  (size_t)kWorkCtrCount / ((size_t)kMaxBatch * kCtrStride), c->groupStreams[slot]));
+        for (int kind = 0; kind < 2; ++kind)
+            HIP_TRY(hipMemset2DAsync(c->fetchCtr + kind * kFetchKind + (size_t)slot * kCtrStride, (size_t)kSegPitch * sizeof(uint32_t), 0, kCtrStride * sizeof(uint32_t),
+                                     (size_t)c->traceDepth * kFetchSegments, c->groupStreams[slot]));
     } else {
         /* the main stream has been made to wait for every pipelined call when that call was issued */
         HIP_TRY(hipMemsetAsync(c->workCtr, 0, kWorkCtrCount * sizeof(uint32_t), s));
+        for (int kind = 0; kind < 2; ++kind)
+            HIP_TRY(hipMemsetAsync(c->fetchCtr + kind * kFetchKind, 0, (size_t)c->traceDepth * kFetchBouncePitch * sizeof(uint32_t), s));
         c->pipeBarrier = true;
     }
-    uint32_t* closestFetch = ctr;
-    uint32_t* shadowFetch = ctr + kWorkCtrSection;
+    uint32_t* closestFetch = c->fetchCtr;
+    uint32_t* shadowFetch = c->fetchCtr + kFetchKind;
     uint32_t* shadowCount = ctr + 2 * kWorkCtrSection;
     uint32_t* closestCount = ctr + 3 * kWorkCtrSection;
     if (c->hintPending && hipEventQuery(c->hintEvent) == hipSuccess) {
@@ -1189,7 +1202,7 @@ static int traceBatch(PtContext* c, Batch bt)
                 SpanGuard sg(c, ST_INTERSECT, gs);
                 if (meshes) {
                     SpanGuard t(c, ST_TRACE, gs);
-                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + row, closestCount + row, c->dc, share);
+                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + (size_t)b * kFetchBouncePitch + rowOff, closestCount + row, c->dc, share);
                 }
                 ptl_prims(gs, V, st, q, gb, b, c->sortOn, count, c->dc, sparseBounce(b));
             }
@@ -1202,7 +1215,7 @@ static int traceBatch(PtContext* c, Batch bt)
                 if (meshes) {
                     if (side) { HIP_TRY(hipEventRecord(c->shadedEvents[sx], gs)); HIP_TRY(hipStreamWaitEvent(ss, c->shadedEvents[sx], 0)); }
                     SpanGuard t(c, ST_SHADOW_TRACE, ss);
-                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + row, shadowCount + row, c->dc, share);
+                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + (size_t)b * kFetchBouncePitch + rowOff, shadowCount + row, c->dc, share);
                     if (side) { HIP_TRY(hipEventRecord(c->shadowDoneEvents[sx], ss)); shadowOpen = true; }
                 }
             }
@@ -1414,6 +1427,7 @@ static int intersectStaged(PtContext* c, const float* origins, const float* dire
     V.useBvh = c->useBvh;
     V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
     uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch * kCtrStride;     /* a slot no bounce of a trace uses */
+    uint32_t* fetch = c->fetchCtr + (size_t)PT_MAX_DEPTH * kFetchBouncePitch;
     const bool count = c->counters != 0;
     /* spans (stage timing, launch counts) take HIP events from a pool that grows on demand: only for callers that may allocate */
     struct MaybeSpan { PtContext* c; int stage; bool on; hipEvent_t a = nullptr;
@@ -1423,7 +1437,7 @@ static int intersectStaged(PtContext* c, const float* origins, const float* dire
         const int m = std::min(chunk, n - first);
         hipError_t e = hipMemcpyAsync(dO, origins + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, kCtrStride * sizeof(uint32_t), c->stream);     /* the whole counter line */
+        if (e == hipSuccess) e = hipMemsetAsync(fetch, 0, (size_t)kFetchBouncePitch * sizeof(uint32_t), c->stream);     /* the eight counter lines of every row */
         if (e == hipSuccess) e = hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) {
             Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
@@ -1431,7 +1445,7 @@ static int intersectStaged(PtContext* c, const float* origins, const float* dire
             ptl_import_rays(c->stream, c->state, c->queues, dO, dD, m);
             if (V.numBvhMeshes > 0) {
                 { MaybeSpan g(c, ST_INTERSECT, spans); ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection); }
-                { MaybeSpan g(c, ST_TRACE, spans); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, count, ctr, ctr + 3 * kWorkCtrSection, c->dc); }
+                { MaybeSpan g(c, ST_TRACE, spans); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, count, fetch, ctr + 3 * kWorkCtrSection, c->dc); }
             }
             { MaybeSpan g(c, ST_INTERSECT, spans); ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, count, c->dc, false); }
             ptl_export_hits(c->stream, c->state, m, dH);
@@ -1493,12 +1507,13 @@ int pt_capture_gbuffer(PtContext* c, int iter, float* normals, float* albedo)
     V.useBvh = c->useBvh;
     V.numBvhMeshes = c->useBvh ? c->bvhMeshGeoms : 0;
     uint32_t* ctr = c->workCtr + (size_t)PT_MAX_DEPTH * kMaxBatch * kCtrStride;     /* a slot no bounce of a trace uses */
+    uint32_t* fetch = c->fetchCtr + (size_t)PT_MAX_DEPTH * kFetchBouncePitch;
     Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
-    HIP_TRY(hipMemsetAsync(ctr, 0, kCtrStride * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(fetch, 0, (size_t)kFetchBouncePitch * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream));
     c->pipeBarrier = true;      /* row 0 of the path state is used on the main stream */
     ptl_camera(c->stream, V, c->cam, bt, c->traceDepth, c->state, c->queues, V.numBvhMeshes > 0 ? ctr + 3 * kWorkCtrSection : nullptr);
-    if (V.numBvhMeshes > 0) ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, ctr, ctr + 3 * kWorkCtrSection, nullptr);
+    if (V.numBvhMeshes > 0) ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, fetch, ctr + 3 * kWorkCtrSection, nullptr);
     ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr, false);
     ptl_gbuffer(c->stream, c->state, V.materials, (int)n, c->gNormals, c->gAlbedo);
     HIP_TRY(hipGetLastError());

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #define PT_LEAF_WAIT 24
 #endif
 constexpr int kRefillThreshold = PT_REFILL;
-constexpr int kSegments = 8;          /* pieces of a work queue = XCDs (private L2s) of the device */
+constexpr int kSegments = kFetchSegments;      /* pieces of a work queue = XCDs (private L2s) of the device */
 constexpr int kLeafWait = PT_LEAF_WAIT;
 
 PT_DEV int nextBvhMesh(const SceneView& S, int from)
@@ -214,8 +214,8 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     /* a short queue does not need every workgroup of the row: those beyond one ray per lane leave at once, without
      * touching the counters (late bounces hold a few thousand rays per row) */
     if ((uint32_t)blockIdx.x * kBlock >= n) return;
-    /* The work queue is cut into kSegments contiguous pieces with a fetch counter each (dwords 0..7 of the row's
-     * counter line).  Workgroups are dealt round-robin over the 8 XCDs, so (linear workgroup id) % 8 names the
+    /* The work queue is cut into kSegments contiguous pieces with a fetch counter each (on a line of its own,
+     * kSegPitch dwords apart).  Workgroups are dealt round-robin over the 8 XCDs, so (linear workgroup id) % 8 names the
      * groups that share an L2: each starts on "its" piece and moves on to the others when that runs dry.  Queues
      * are filed in pixel / slot order, so a piece is a coherent part of the image and an XCD's L2 mostly sees one
      * part of the BVH. */
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 if (segsLeft == 0) { if (fetch) exhausted = true; break; }
                 if (needScan) {
                     needScan = false;
-                    /* the piece this wave was on is used up: read all eight counters (one cache line) and go to the next
+                    /* the piece this wave was on is used up: read all eight counters and go to the next
                      * piece that still has entries, instead of finding every dry piece with an atomic of its own —
                      * at the end of a launch thousands of waves do that at once, and their atomics on one line took
                      * longer than the last rays.  The counters only grow, so a stale value costs at worst the atomic
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
 #pragma unroll
                     for (int k = 0; k < kSegments; ++k) {
                         const uint32_t len = (uint32_t)(((unsigned long long)n * (unsigned)(k + 1)) / kSegments) - (uint32_t)(((unsigned long long)n * (unsigned)k) / kSegments);
-                        const uint32_t cur = __hip_atomic_load(ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t cur = __hip_atomic_load(ctr + k * kSegPitch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const int dist = (k - seg) & (kSegments - 1);
                         if (cur < len && dist < foundDist) foundDist = dist;
                     }
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                 const uint32_t want = (uint32_t)__builtin_popcountll(fm);
                 const int leader = __builtin_ctzll(fm);
                 uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(ctr + seg, want);
+                if (lane == leader) base = atomicAdd(ctr + seg * kSegPitch, want);
                 base = (uint32_t)__shfl((int)base, leader);
                 if (base + want >= segLen) { seg = (seg + 1) % kSegments; needScan = true; }     /* this piece is used up */
                 if (fetch) {
