@@ -41,9 +41,10 @@ constexpr int kCtrStride = 32;        /* dwords between work counters: one 128-b
 constexpr int kCtrRows = 512;         /* rows (iterations of a launch group) the counter arrays are laid out for */
 constexpr int kFetchSegments = 8;     /* fetch counters per work queue, see k_trace */
 /* Fetch counters of the traversal kernel: [bounce][segment][row], a 128-byte line each.  The eight counters of one
- * queue sit on lines of their own, kSegPitch dwords apart: atomics on one line are served one after the other
- * (about 60 M per second per line on this device, whatever the address inside it), and a launch of its own over two
- * million rays makes 66 000 of them — with all eight counters on one line that, not the traversal, set its duration. */
+ * queue sit on lines of their own, kSegPitch dwords apart: atomics on one line are served one after the other,
+ * whatever the address inside it, and every wave waits for its fetch.  A launch of its own over two million rays
+ * makes 66 000 fetches; with all eight counters on one line and 4 096 waves contending they came back at about 60 M
+ * per second, and that, not the traversal, set the launch's duration (1.1 ms; 0.78 ms with a line per counter). */
 constexpr int kSegPitch = kCtrRows * kCtrStride;
 constexpr int kFetchBouncePitch = kFetchSegments * kSegPitch;
 constexpr int kMaxBuckets = 256;     /* material ids + the miss bucket handled by the sort   */
