@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #define PT_REFILL 24
 #endif
 #ifndef PT_TRACE_MINWAVES
-#define PT_TRACE_MINWAVES 5
+#define PT_TRACE_MINWAVES 4
 #endif
 #ifndef PT_SHADE_MINWAVES
 #define PT_SHADE_MINWAVES 5
@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
         if (__ballot(trav) == 0 || __builtin_popcountll(idle) >= kRefillThreshold) {
             /* epilogues and refills run together for all idle lanes */
             bool fetch = !trav && !exhausted;
+            if (done && travRecheck(S, tv)) { trav = true; done = false; fetch = false; }
             if (done) {
                 const DGeom& g = S.geoms[gi];
                 F3 nn; F2 uv; int mat = 0, tri = -1;

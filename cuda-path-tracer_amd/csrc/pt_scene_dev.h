@@ -71,6 +71,7 @@ struct SceneView {
     const float4* nodes;
     const float4* triHot;
     const float4* triCold;
+    const float4* triBox;       /* 2 per leaf-order triangle: min, max of its leaf in the host BVH; a hit counts only if the ray passes that box */
     const int* leafOfOrig;
     const DTexture* textures;
     const DLight* lights;
@@ -291,12 +292,11 @@ struct MeshTrav {
     F3 lo, ld, invDir;          /* ray in the mesh's object space */
     float closestT;
     int best, bestRank;
-    F3 bary;
+    F3 bary;                    /* .y, .z: barycentrics of the closest hit; .x: non-zero on the second, checking walk of a ray (see passesHostLeafBox) */
     int sp, ref;
     int nodeStart, triStart;    /* of the mesh being walked, kept in registers: a per-step reload from the geom
                                    record would put one more dependent memory access in front of every node fetch */
-    bool fast;                  /* origin and reciprocal direction are finite: no NaN can arise in a slab test */
-    uint32_t selX, selY, selZ;  /* fast rays: byte offset (0 or 48) of the plane array a slab is entered through, per axis */
+    uint32_t selX, selY, selZ;  /* byte offset (0 or 48) of the plane array a slab is entered through, per axis */
 };
 
 PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
@@ -313,12 +313,68 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.nodeStart = g.nodeStart;
     tv.triStart = g.triStart;
     const float INF = __builtin_inff();
-    tv.fast = __builtin_fabsf(tv.invDir.x) < INF && __builtin_fabsf(tv.invDir.y) < INF && __builtin_fabsf(tv.invDir.z) < INF &&
-              __builtin_fabsf(tv.lo.x) < INF && __builtin_fabsf(tv.lo.y) < INF && __builtin_fabsf(tv.lo.z) < INF;
+    /* A ray with a NaN or an infinity in its origin or direction hits no triangle in the reference either (every
+     * barycentric test or the distance test fails, or the distance comes out infinite), whatever its box tests say.
+     * Its origin is moved to infinity: every walked box then fails (slab distances of -inf or +inf on all planes),
+     * and a triangle test against it fails as well. */
+    const bool valid = __builtin_fabsf(tv.lo.x) < INF && __builtin_fabsf(tv.lo.y) < INF && __builtin_fabsf(tv.lo.z) < INF &&
+                       __builtin_fabsf(tv.ld.x) < INF && __builtin_fabsf(tv.ld.y) < INF && __builtin_fabsf(tv.ld.z) < INF;
+    if (!valid) tv.lo = f3(INF);
+    /* The walked boxes are tested with a finite reciprocal: a zero direction component gets 1e25 instead of infinity.
+     * With the origin between the two planes of that axis the slab interval then covers every distance that matters
+     * (or ends at 0 when the origin lies in a plane, which only the ray's own starting point needs); outside them it
+     * lies beyond any hit or behind the origin, as it should — and 0 x infinity, a NaN that the plain min / max
+     * would take for a miss, cannot arise.  The host leaf box test of a hit uses the true reciprocal. */
+    if (!(__builtin_fabsf(tv.invDir.x) < INF)) tv.invDir.x = 1e25f;
+    if (!(__builtin_fabsf(tv.invDir.y) < INF)) tv.invDir.y = 1e25f;
+    if (!(__builtin_fabsf(tv.invDir.z) < INF)) tv.invDir.z = 1e25f;
     /* a node stores its four child boxes as six plane arrays: min x, y, z at bytes 0, 16, 32 and max x, y, z at 48, 64, 80 */
     tv.selX = tv.invDir.x < 0.0f ? 48u : 0u;
     tv.selY = tv.invDir.y < 0.0f ? 48u : 0u;
     tv.selZ = tv.invDir.z < 0.0f ? 48u : 0u;
+}
+
+/* The boxes of the hierarchy that is walked only have to be conservative: a triangle the reference would hit must
+ * never be cut off by them.  Their slab distances are computed with rounding (each product is within two units in
+ * the last place of its exact value), and the triangle test has an error of its own of a few parts in ten million
+ * of the distance; both scale with the distances themselves.  The interval of a walked box is therefore widened by
+ * 2^-15 of its far end before it is compared with anything (and the closest distance likewise before an entry distance
+ * is compared with it) — about a hundred times those errors, at any scale. */
+constexpr float kBoxSlack = 3.0517578125e-05f;
+PT_DEV float slackFar(float t) { return __builtin_fmaf(__builtin_fabsf(t), kBoxSlack, t); }
+
+/* intersectAABB (src/intersections.cu:248-266) on the box of the host-BVH leaf that holds leaf-order triangle `tri`,
+ * in the reference's arithmetic (component-wise min / max as compare-and-select, NaN behaviour included).  The
+ * reference tests a leaf's triangles only when this holds, so a hit found by walking other boxes counts only then.
+ * A hit that fails is a rounding accident at the rim of a leaf box (the triangle lies inside it), so the walk does not
+ * look at the box per hit: the closest hit is checked once when the walk is over (travRecheck), and only if that
+ * fails is the ray walked again with the check on every new closest hit (MeshTrav::bary.x set) — the closest of
+ * the hits that pass. */
+PT_DEV bool passesHostLeafBox(const SceneView& S, const MeshTrav& tv, int tri)
+{
+    const float4* b = S.triBox + 2 * ((size_t)tv.triStart + (size_t)tri);
+    const float4 bmin = b[0], bmax = b[1];
+    const F3 lo = tv.lo, invDir = 1.0f / tv.ld;       /* the true reciprocal, infinities included */
+    float ax0 = (bmin.x - lo.x) * invDir.x, ax1 = (bmax.x - lo.x) * invDir.x;
+    float ay0 = (bmin.y - lo.y) * invDir.y, ay1 = (bmax.y - lo.y) * invDir.y;
+    float az0 = (bmin.z - lo.z) * invDir.z, az1 = (bmax.z - lo.z) * invDir.z;
+    float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));
+    float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));
+    return tMax >= tMin && tMax >= 0.0f;
+}
+
+/* After a walk has ended: true if its closest hit is one the reference would not have looked at; the walk of this
+ * mesh then starts over from the root, checking every new closest hit as it is found. */
+PT_DEV bool travRecheck(const SceneView& S, MeshTrav& tv)
+{
+    if (tv.best < 0 || tv.bary.x != 0.0f || passesHostLeafBox(S, tv, tv.best)) return false;
+    tv.closestT = 3.402823466e+38f;
+    tv.best = -1;
+    tv.bestRank = 0x7fffffff;
+    tv.bary.x = 1.0f;
+    tv.sp = 0;
+    tv.ref = 0;
+    return true;
 }
 
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
@@ -332,9 +388,11 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         float tk[4];
         int rk[4];
         const F3 lo = tv.lo, invDir = tv.invDir;
-        const float closestT = tv.closestT;
-        if (tv.fast) {
-            /* With a finite origin and reciprocal direction no NaN can arise, and for a box with min <= max the
+        /* the slack of the box tests (kBoxSlack) sits on two of the three comparisons' far sides: the exit distance and
+         * the closest hit so far; entry distances go to the stack as computed and meet the same widened bound at pop time */
+        const float closestSlack = __builtin_fminf(slackFar(tv.closestT), 3.402823466e+38f);       /* finite: an empty slot's +inf must still fail */
+        {
+            /* With a finite origin and a finite reciprocal direction (travInit) no NaN can arise, and for a box with min <= max the
              * smaller of (min - o) * inv and (max - o) * inv is the one whose plane the ray's direction sign names
              * (subtraction and the multiplication by inv are monotone).  The entry planes are therefore picked by
              * address — three offsets per ray — and the interval is max3 of the entry distances, min3 of the exit
@@ -373,36 +431,13 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
 #define PT_CHILD_FAST(k, H, E, C)                                                                   \
             {                                                                                        \
                 float tMin = __builtin_fmaxf(__builtin_fmaxf(nx##H.E, ny##H.E), nz##H.E);             \
-                float tMax = __builtin_fminf(__builtin_fminf(fx##H.E, fy##H.E), fz##H.E);             \
-                bool in = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT);                      \
+                float tMax = slackFar(__builtin_fminf(__builtin_fminf(fx##H.E, fy##H.E), fz##H.E));   \
+                bool in = (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestSlack);                  \
                 tk[k] = in ? tMin : INF;                                                             \
                 rk[k] = __float_as_int(rf.C);                                                        \
             }
             PT_CHILD_FAST(0, 0, x, x) PT_CHILD_FAST(1, 0, y, y) PT_CHILD_FAST(2, 1, x, z) PT_CHILD_FAST(3, 1, y, w)
 #undef PT_CHILD_FAST
-        } else {
-            const float4* q = S.nodes + 8 * ((size_t)tv.nodeStart + (size_t)ref);
-            float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-            float4 rf = q[6];
-            if (COUNT) {
-                cnt.nodes++;
-                cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
-                             (__float_as_int(rf.z) != kEmptyRef) + (__float_as_int(rf.w) != kEmptyRef);
-            }
-#define PT_CHILD(k, C)                                                                              \
-            {                                                                                        \
-                float ax0 = (mnx.C - lo.x) * invDir.x, ax1 = (mxx.C - lo.x) * invDir.x;               \
-                float ay0 = (mny.C - lo.y) * invDir.y, ay1 = (mxy.C - lo.y) * invDir.y;               \
-                float az0 = (mnz.C - lo.z) * invDir.z, az1 = (mxz.C - lo.z) * invDir.z;               \
-                float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));    \
-                float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));    \
-                int cr = __float_as_int(rf.C);                                                       \
-                bool in = (cr != kEmptyRef) && (tMax >= tMin && tMax >= 0.0f) && !(tMin > closestT); \
-                tk[k] = in ? tMin : INF;                                                             \
-                rk[k] = cr;                                                                          \
-            }
-            PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
-#undef PT_CHILD
         }
         /* nearest first: 5-exchange network on (distance, ref) */
 #define PT_CSWAP(i, j) { bool sw = tk[j] < tk[i]; float tt_ = sw ? tk[j] : tk[i]; float tu_ = sw ? tk[i] : tk[j]; \
@@ -444,38 +479,41 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
             if (COUNT) cnt.tris++;
             if (tt > 0.0f && !(tt > tv.closestT)) {
                 int rank = __float_as_int(rc.z);
-                if (tt < tv.closestT || rank < tv.bestRank) { tv.closestT = tt; tv.bary = bary; tv.best = first + i; tv.bestRank = rank; }
+                if (tt < tv.closestT || rank < tv.bestRank) {
+                    /* a new closest hit — if the reference would have looked at this triangle at all */
+                    if (tv.bary.x == 0.0f || passesHostLeafBox(S, tv, first + i)) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
+                }
             }
             ra = na; rb = nb; rc = nc;
         }
     }
     /* pop the next entry that can still hold a closer (or equal) hit */
     int sp = tv.sp;
+    const float popBound = slackFar(tv.closestT);
     if (sp <= kLdsStack) {
         /* everything left is in LDS */
         while (sp > 0) {
             sp--;
             const int r2 = stack[sp * kBlock];
             const float t = __int_as_float(stack[(kLdsStack + sp) * kBlock]);
-            if (!(t > tv.closestT)) { tv.sp = sp; tv.ref = r2; return true; }
+            if (!(t > popBound)) { tv.sp = sp; tv.ref = r2; return true; }
         }
-        tv.sp = 0;
-        return false;
-    }
-    while (sp > 0) {
-        sp--;
-        float t;
-        int r2;
-        /* the empty asm statements keep the two address spaces apart: merged into one generic-pointer
-         * load, every pop would be a flat access that waits for all outstanding vector memory as well */
-        if (sp < kLdsStack) {
-            r2 = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]);
-            asm volatile("" : "+v"(r2), "+v"(t));
-        } else {
-            r2 = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack];
-            asm volatile("" : "+v"(r2), "+v"(t));
+    } else {
+        while (sp > 0) {
+            sp--;
+            float t;
+            int r2;
+            /* the empty asm statements keep the two address spaces apart: merged into one generic-pointer
+             * load, every pop would be a flat access that waits for all outstanding vector memory as well */
+            if (sp < kLdsStack) {
+                r2 = stack[sp * kBlock]; t = __int_as_float(stack[(kLdsStack + sp) * kBlock]);
+                asm volatile("" : "+v"(r2), "+v"(t));
+            } else {
+                r2 = ovRef[sp - kLdsStack]; t = ovT[sp - kLdsStack];
+                asm volatile("" : "+v"(r2), "+v"(t));
+            }
+            if (!(t > popBound)) { tv.sp = sp; tv.ref = r2; return true; }
         }
-        if (!(t > tv.closestT)) { tv.sp = sp; tv.ref = r2; return true; }
     }
     tv.sp = 0;
     return false;
@@ -577,12 +615,11 @@ PT_DEV float inlineOccluderDistance(const SceneView& S, const DGeom& g, const Ra
 /* The traversal's first step, taken ahead of time: true when the ray fails all four child boxes of the mesh's
  * root node, with the arithmetic travStep uses for them (same loads, same operations, closest distance still at
  * its initial value).  Such a ray leaves the traversal empty-handed after that one step, so it need not be queued.
- * Rays outside the fast form (a non-finite origin or reciprocal direction) are kept. */
+ * (A ray with a non-finite origin or direction fails them all, see travInit: it hits nothing.) */
 PT_DEV bool failsRootNode(const SceneView& S, const DGeom& g, const Ray& r)
 {
     MeshTrav tv;
     travInit(g, r, tv);
-    if (!tv.fast) return false;
     const F3 lo = tv.lo, invDir = tv.invDir;
     const char* base = (const char*)S.nodes;
     const uint32_t off = (uint32_t)tv.nodeStart * 128u;
@@ -597,7 +634,7 @@ PT_DEV bool failsRootNode(const SceneView& S, const DGeom& g, const Ray& r)
 #define PT_CHILD_ROOT(C)                                                                            \
     {                                                                                                \
         float tMin = __builtin_fmaxf(__builtin_fmaxf((nX.C - lo.x) * invDir.x, (nY.C - lo.y) * invDir.y), (nZ.C - lo.z) * invDir.z); \
-        float tMax = __builtin_fminf(__builtin_fminf((fX.C - lo.x) * invDir.x, (fY.C - lo.y) * invDir.y), (fZ.C - lo.z) * invDir.z); \
+        float tMax = slackFar(__builtin_fminf(__builtin_fminf((fX.C - lo.x) * invDir.x, (fY.C - lo.y) * invDir.y), (fZ.C - lo.z) * invDir.z)); \
         any = any || ((tMax >= tMin && tMax >= 0.0f) && !(tMin > tv.closestT));                      \
     }
     PT_CHILD_ROOT(x) PT_CHILD_ROOT(y) PT_CHILD_ROOT(z) PT_CHILD_ROOT(w)
