@@ -280,10 +280,17 @@ PT_DEV float hitTriangleRec(float4 a, float4 b, float4 c, F3 lo, F3 ld, F3& bary
  * whose LEAF box passes the slab test, the first-visited one among equals (strict '<').
  * Ancestor boxes only accelerate: slab intervals of nested boxes nest in IEEE arithmetic
  * (subtraction and multiplication by the same 1/d are monotone), so a ray that passes a leaf
- * box passes every ancestor.  This traversal therefore uses its own structure above the
- * leaves (4-wide nodes, nearest child first, entry distance kept on the stack for pruning at
- * pop time) and reproduces the reference's choice among equals with a per-triangle visit rank
- * computed on the host from the reference's order.
+ * box passes every ancestor.  The leaf boxes therefore are a FILTER on triangle hits, and the
+ * hierarchy that is walked to find those hits is free.  This traversal walks its own: 4-wide
+ * nodes down to boxes around single triangles, nearest child first, entry distance kept on
+ * the stack for pruning at pop time, boxes that only have to be conservative (kBoxSlack).  A
+ * closest hit is checked against the box of its leaf in the reference's BVH, with the
+ * reference's arithmetic (passesHostLeafBox), and the reference's choice among equals is
+ * reproduced with a per-triangle visit rank computed on the host from the reference's order.
+ * (The reference also skips a node whose entry distance exceeds the closest hit so far.  For
+ * boxes that contain their triangles that can only skip triangles that would lose anyway —
+ * up to rounding at a box face, where its result depends on its visiting order; this
+ * traversal then returns the closest hit that passes its leaf box.)
  *
  * stack: this lane's column of a [kStackDepth][kBlock] LDS array (refs in rows 0..kLdsStack-1,
  * entry distances in the rows above); deeper entries spill to private memory.

@@ -109,7 +109,12 @@ typedef struct PtBvhNode {
 /* One mesh = the triangles of one glTF object (src/sceneStructs.h:48-53),
  * optionally with a prebuilt BVH (output of pt_bvh_build).  When nodes is
  * NULL pt_create builds the BVH itself, as initializeBVHs does
- * (src/pathtrace.cu:269-334). */
+ * (src/pathtrace.cu:269-334).  A prebuilt BVH decides, as in the reference,
+ * which triangle hits count (those whose leaf box the ray passes) and which of
+ * two hits at the same distance wins (the one the reference visits first); its
+ * boxes must contain the triangles below them, as any builder's do — for
+ * boxes that do not, the reference's own result depends on its visiting order
+ * and is not reproduced. */
 typedef struct PtMesh {
     const PtTriangle* triangles;
     int32_t triangleCount;

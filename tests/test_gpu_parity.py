@@ -313,6 +313,72 @@ def test_one_iteration_calls_in_flight_bit_exact(pt, scenes, orc, gpu_ok):
     assert _same_bits(tr.image(), sums[11])
 
 
+def _desc_with_bvh(pt, sc, mesh, nodes, indices, keep):
+    """A copy of the scene description in which mesh `mesh` carries the given host BVH."""
+    d = pt.PtSceneDesc.from_buffer_copy(sc.desc.contents)
+    meshes = (pt.PtMesh * d.meshCount)()
+    for m in range(d.meshCount):
+        meshes[m] = sc.desc.contents.meshes[m]
+    nodes = np.ascontiguousarray(nodes)
+    indices = np.ascontiguousarray(indices, np.int32)
+    meshes[mesh].nodes = nodes.ctypes.data
+    meshes[mesh].nodeCount = len(nodes)
+    meshes[mesh].triangleIndices = indices.ctypes.data
+    meshes[mesh].triangleIndexCount = len(indices)
+    d.meshes = C.cast(meshes, C.POINTER(pt.PtMesh))
+    keep.extend([d, meshes, nodes, indices, sc])
+    return C.pointer(d)
+
+
+def test_host_leaf_boxes_decide_which_triangles_count(pt, scenes, orc, gpu_ok):
+    """The library walks boxes of its own, down to single triangles; which triangle hits count is decided by the leaf
+    boxes of the host BVH, as in the reference (a leaf's triangles are tested only when the ray passes the leaf's box).
+    With the host BVH the library builds itself a hit fails its leaf box only by a rounding accident, so this test hands
+    in a BVH whose leaf boxes have their far part (seen from the camera) cut away: rays that enter a leaf box only
+    there still hit its triangles geometrically, but the reference does not look at them, and the closest hit falls
+    through to a triangle behind.  The cut keeps every box's near faces, so a ray that passes a cut box enters it where
+    it entered the full one and the reference's distance prune sees the same entry distance (its result then does not
+    depend on its visiting order, which is all this library reproduces).  The second, checking walk of a ray runs
+    for every ray whose closest geometric hit does not count."""
+    sc = scenes.make_scene("dragon", res=(160, 96), depth=8, grid=(40, 41), env_size=(64, 32), tex_size=16)
+    d0 = sc.desc.contents
+    mesh = 0
+    gi = [i for i in range(d0.geomCount) if d0.geoms[i].type == pt.PT_GLTF_MESH and d0.geoms[i].meshIndex == mesh][0]
+    inv = np.array(list(d0.geoms[gi].inverseTransform), np.float64).reshape(4, 4).T        # column-major in memory
+    eye = (inv @ np.array(list(d0.camera.position) + [1.0]))[:3]
+    n = int(d0.meshes[mesh].triangleCount)
+    tris = np.frombuffer(C.string_at(d0.meshes[mesh].triangles, n * pt.TRI_DTYPE.itemsize), dtype=pt.TRI_DTYPE).copy()
+    nodes, idx, _ = pt.bvh_build(tris)
+    nd = nodes.copy()
+    cut = 0
+    for i in np.flatnonzero(nd["leftChild"] == -1):
+        lo, hi = nd["bmin"][i].astype(np.float64), nd["bmax"][i].astype(np.float64)
+        gap = np.where(eye < lo, lo - eye, np.where(eye > hi, eye - hi, np.inf))
+        gap = np.where(hi - lo > 0, gap, np.inf)
+        k = int(np.argmin(gap))                 # the axis along which the camera looks at this box most obliquely
+        if not np.isfinite(gap[k]):
+            continue
+        if eye[k] < lo[k]:
+            nd["bmax"][i][k] = np.float32(lo[k] + 0.3 * (hi[k] - lo[k]))
+        else:
+            nd["bmin"][i][k] = np.float32(hi[k] - 0.3 * (hi[k] - lo[k]))
+        cut += 1
+    assert cut > 100
+    keep = []
+    desc = _desc_with_bvh(pt, sc, mesh, nd, idx, keep)
+    tr = pt.Tracer(desc)
+    o = orc.Oracle(pt, desc, orc.MATH_DET)
+    ro, rd = tr.camera_rays(1)
+    g, ob = tr.intersect(ro, rd), o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    # the cut boxes do change the picture: mesh hits are lost or replaced by triangles behind
+    full = pt.Tracer(sc).intersect(ro, rd)
+    on_mesh = full["triangle"] >= 0
+    changed = on_mesh & ((g["triangle"] != full["triangle"]) | (g["t"] != full["t"]))
+    assert changed.sum() > 0.02 * on_mesh.sum(), (int(changed.sum()), int(on_mesh.sum()))
+    assert (changed & (g["triangle"] >= 0)).sum() > 50        # fell through to another triangle, not just to a miss
+
+
 def test_launch_shapes_and_largest_groups_bit_exact(pt, scenes, orc, gpu_ok):
     """Groups of 12 iterations or more go through the library's launch-shape trial (one, two, three streams, one stream
     with the shadow traversal in line, then the kept shape), and a group may hold up to 512 iterations: the sum is
