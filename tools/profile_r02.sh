@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel trace + hardware-counter passes of one bench.py workload on the GPU box (each pass is a run of its own).
-#   tools/profile_r02.sh <workload> [out dir under gpurun_out]
+#   tools/profile_r02.sh <workload> [out dir under gpurun_out]      (KT_ONLY=1: the kernel trace alone)
 # then, here:   python tools/pmc_workload.py gpurun_out/prof_<workload> <workload>
 set -e -o pipefail
 W=${1:-dragon}
@@ -13,6 +13,7 @@ export TMPDIR=/tmp
 ARGS="--workload $W --no-cpu-baseline --no-extras --steps 2 --warmup 0"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/kt_bench.json"
 echo "kernel trace done"
+if [ -n "$KT_ONLY" ]; then exit 0; fi
 timeout -s KILL 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/sq_bench.json"
 echo "sq pass done"
 timeout -s KILL 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq2" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/sq2_bench.json"
