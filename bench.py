@@ -338,8 +338,20 @@ def main():
             avg_ms = ms_dom / max(launches, 1)
             units = st.pathBounces / max(launches, 1)
             achieved = b_pb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            # traffic = HBM bytes per launch from a profiled run of this workload (profiles/pmc_<workload>.json, per path-bounce)
+            k = pmc.get(dom, {})
+            traffic_pb = k.get("hbm_bytes_per_path_bounce")
+            traffic = round(traffic_pb * units) if traffic_pb else None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_gbs": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None),
+                        "hbm_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None),
+                        "issue_utilisation": k.get("valu_issue_utilisation"), "lane_utilisation": k.get("valu_lane_utilisation"),
+                        "l2_hit_rate": k.get("l2_hit_rate"),
+                        "counters_from": ("profiles/pmc_%s.json (rocprofv3 --pmc passes of this workload)" % args.workload) if k else None,
+                        "note": "frac prices the algorithmic bytes of the stage against HBM; the stage reaches its paths through a sorted "
+                                "queue and gathers 16-byte records, each of which pulls a whole line, so the HBM traffic the counters see "
+                                "(traffic, hbm_frac) is several times the algorithmic bytes",
                         "alg_bytes_per_path_bounce": b_pb, "path_bounces_per_launch": round(units, 1),
                         "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                         "stage_ms_per_spp": {k2: round(v / max(spp_rank, 1), 4) for k2, v in stages.items()}, "measured_in": measured_in}

@@ -68,9 +68,11 @@ def main():
     rl = bench["roofline"]
     depth, steps = bench["config"]["depth"], bench["steps"]
     n = steps * depth
-    rays_closest = rl["rays_per_launch"] * rl["launches"]
     spp = bench["config"]["spp_per_step_per_gpu"] * steps
-    rays = {"k_trace(closest)": rays_closest, "k_trace(shadow)": bench["config"]["shadow_rays_per_spp"] * spp}
+    pb_total = bench["config"].get("path_bounces_per_spp", 0.0) * spp
+    rays = {}
+    if "rays_per_launch" in rl:         # scenes without a BVH mesh have no traversal launches
+        rays = {"k_trace(closest)": rl["rays_per_launch"] * rl["launches"], "k_trace(shadow)": bench["config"]["shadow_rays_per_spp"] * spp}
     passes = {p: load(os.path.join(base, p)) for p in ("sq", "sq2", "l2", "fetch", "write")}
     res = {"_workload": workload, "_bench_line_of_the_sq_pass": {k: bench[k] for k in ("value", "ms_per_step")},
            "_method": "rocprofv3 --pmc, one pass per counter group (tools/profile_r02.sh), sums over the last %d dispatches of each kernel "
@@ -120,6 +122,10 @@ def main():
         e["hbm_write_bytes"] = round(wr.get("WRITE_SIZE", 0.0) * 1024.0)
         if k in rays and rays[k] > 0:
             e["hbm_bytes_per_ray"] = round(hbm / rays[k], 2)
+        if k in ("k_shade", "k_prims") and pb_total > 0:
+            # the one-thread-per-slot stages handle every path-bounce once
+            e["hbm_bytes_per_path_bounce"] = round(hbm / pb_total, 2)
+            e["valu_wave_instructions_per_64_path_bounces"] = round(sq.get("SQ_INSTS_VALU", 0.0) * 64.0 / pb_total, 1)
         fsec = fe["_ns"] * 1e-9 if fe.get("_ns") else 0
         e["hbm_gbs_under_counters"] = round(hbm / fsec / 1e9, 1) if fsec else None
         for c in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_SMEM"):
