@@ -217,7 +217,7 @@ int allocBatchState(PtContext* c, int batch)
 #define BA(ptr, count, zero) if (rc == PT_OK) rc = batchAlloc(owned, &(ptr), (count), (zero))
     BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
     BA(P.hitA, N * B, false); BA(P.hitB, N * B, false); BA(P.hitTri, N * B, false);
-    BA(P.shO, N * B, false); BA(P.shD, N * B, false); BA(P.shC, N * B, false); BA(P.workQueue, N * B, false); BA(P.traceQueue, N * B, false);
+    BA(P.shRec, N * B * 3, false); BA(P.traceQueue, N * B, false);
     BA(P.image, N * B * 3, true);
     BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);
     BA(Q.blockHist, (size_t)Q.numBuckets * Q.numBlocks * B, false);

@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0; best.uv.y = 0; best.geom = -1; best.tri = -1;
     float shDist = 0.0f;        /* shadow mode: distance to the light sample */
     int shLight = -1;           /* shadow mode: geom of the light, -1 for an environment ray */
+    int shSlot = 0;             /* shadow mode: queue position of the lane's ray (its colour record is read when the verdict is in) */
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     /* settle the path colour, then the image add the shade stage held back */
                     float4 c = st.col[pix];
                     if (!blocked) {
-                        float4 v = st.shC[pix];
+                        float4 v = st.shRec[3 * (size_t)shSlot + 2];
                         c.x = v.x; c.y = v.y; c.z = v.z;
                         st.col[pix] = c;
                     }
@@ -337,8 +338,10 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
                         } else {
-                            pix = st.workQueue[sidx];
-                            float4 o = st.shO[pix], d = st.shD[pix];
+                            const float4* rec = st.shRec + 3 * (size_t)sidx;
+                            float4 o = rec[0], d = rec[1];
+                            pix = __float_as_int(rec[2].w);
+                            shSlot = (int)sidx;
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             shDist = o.w;
                             shLight = __float_as_int(d.w);
@@ -634,10 +637,10 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         /* shadow queue append */
         const int shIdx = blockAppendIndex(sq.pending, shadowCount + blockIdx.y * kCtrStride, s_tmp);
         if (shIdx >= 0) {
-            st.workQueue[shIdx] = pix;
-            st.shO[pix] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
-            st.shD[pix] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
-            st.shC[pix] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, 0.0f);
+            float4* rec = st.shRec + 3 * (size_t)shIdx;
+            rec[0] = make_float4(sq.o.x, sq.o.y, sq.o.z, sq.dist);
+            rec[1] = make_float4(sq.d.x, sq.d.y, sq.d.z, __int_as_float(sq.lightGeom));
+            rec[2] = make_float4(sq.colorVisible.x, sq.colorVisible.y, sq.colorVisible.z, __int_as_float(pix));
         }
         unsigned long long m = __ballot(alive);
         if (laneId() == 0) s_alive[tid >> 6] = (int)__builtin_popcountll(m);

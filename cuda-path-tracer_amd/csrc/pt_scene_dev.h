@@ -118,12 +118,11 @@ struct PathState {
     float4* hitB;
     float* image;                   /* W*H*3: this iteration's contribution inside the kernels */
     int* hitTri;                    /* mesh-local triangle of the hit (parity hook) */
-    /* shadow rays whose mesh part is still to be traced: (origin, max distance) (direction, light geom
-       or -1 for the environment) (path colour if the ray turns out unoccluded) */
-    float4* shO;
-    float4* shD;
-    float4* shC;
-    int* workQueue;                 /* pixels with a pending shadow ray, in arrival order */
+    /* shadow rays whose mesh part is still to be traced, in arrival order, three records each: (origin, max distance)
+       (direction, light geom or -1 for the environment) (path colour if the ray turns out unoccluded, pixel).  The
+       shade stage appends them — consecutive lanes write consecutive records — and the shadow traversal reads them
+       by queue position, so neither side gathers or scatters by pixel. */
+    float4* shRec;
     int* traceQueue;                /* pixels whose ray may hit a BVH mesh, in arrival order (filled by the stage that
                                        creates the ray: camera, shade) */
     size_t numPixels;
@@ -132,7 +131,7 @@ struct PathState {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
         r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.image += 3 * off;
-        r.hitTri += off; r.shO += off; r.shD += off; r.shC += off; r.workQueue += off; r.traceQueue += off;
+        r.hitTri += off; r.shRec += 3 * off; r.traceQueue += off;
         return r;
     }
 };
