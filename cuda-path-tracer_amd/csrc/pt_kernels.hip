@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #define PT_SHADE_MINWAVES 5
 #endif
 #ifndef PT_LEAF_WAIT
-#define PT_LEAF_WAIT 24
+#define PT_LEAF_WAIT 20
 #endif
 constexpr int kRefillThreshold = PT_REFILL;
 constexpr int kSegments = kFetchSegments;      /* pieces of a work queue = XCDs (private L2s) of the device */
