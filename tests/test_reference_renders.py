@@ -9,7 +9,6 @@ these tests render the same scenes and compare 8 x 8 block means and whole-image
 Bars (8-bit levels, stated per test): the reference's images are finite-sample renders themselves, so the block RMSE
 floors at their own noise; the whole-image mean does not.
 """
-import importlib
 import json
 import os
 
