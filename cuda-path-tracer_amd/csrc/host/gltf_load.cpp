@@ -25,7 +25,7 @@
  *    interleaved file imports the way the reference imports it;
  * Deliberate differences: the scalars the reference leaves uninitialised in an imported Material (specular exponent, index of
  * refraction, subsurface radius / scale / anisotropy / enabled, src/scene.cpp:96) are 0, 1.5, 0, 0, 0, 0;
- * images that are neither 8-bit PNG nor sequential 8-bit JPEG (16-bit PNG, progressive JPEG, other formats) are
+ * images that are neither 8-bit PNG nor 8-bit Huffman-coded JPEG (16-bit PNG, arithmetic-coded JPEG, other formats) are
  * skipped with a warning (texture index -1) instead of failing the load.
  */
 #include "gltf_load.h"

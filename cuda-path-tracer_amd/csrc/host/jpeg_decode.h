@@ -1,5 +1,5 @@
 /*
- * jpeg_decode.h — baseline / extended-sequential JPEG (8 bits per sample, Huffman) to interleaved RGBA8.
+ * jpeg_decode.h — baseline / extended-sequential / progressive JPEG (8 bits per sample, Huffman) to interleaved RGBA8.
  *
  * The reference gets texture pixels from tinygltf -> stb_image with four requested components
  * (external/include/tiny_gltf.h LoadImageData; src/scene.cpp:69-77).  JPEG decoding is not bit-defined by
@@ -8,9 +8,12 @@
  * inverse DCT with 12-bit constants, two extra bits after the column pass and +128 folded into the row pass
  * (:2426-2524), triangle-filter chroma upsampling for 2x1 / 1x2 / 2x2 and sample repetition otherwise
  * (:3465-3527, :3646-3655, row stepping :3926-3941), fixed-point YCbCr -> RGB (:3659-3683), Adobe / JFIF
- * marker rules for RGB, CMYK and YCCK data (:3879, :3942-3983).  No known-answer vectors for this decoder
- * ship with the reference: its agreement with stb_image is by construction, not by test.
- * Progressive and arithmetic-coded files are refused.
+ * marker rules for RGB, CMYK and YCCK data (:3879, :3942-3983).  Progressive files (SOF2) keep their coefficients,
+ * undequantised, until the last scan: DC first / refinement scans and AC first / refinement scans with end-of-band
+ * runs as stb_image reads them (:2265-2412, scan loop :3011-3068), then every block is dequantised and transformed
+ * once (:3073-3097).  tests/test_reference_build.py compares the pixels with stb_image's, built from the reference's
+ * tree, on sequential and progressive files.  Arithmetic-coded and differential files are refused, as stb_image
+ * refuses them.
  */
 #pragma once
 #include <cstdint>
@@ -56,6 +59,8 @@ struct Component {
     int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dcPred = 0;
     int x = 0, y = 0, w2 = 0, h2 = 0;
     std::vector<uint8_t> data;
+    std::vector<short> coeff;   /* progressive files: 64 coefficients per block, natural order, blocks in rows of coeffW */
+    int coeffW = 0;
 };
 
 class Decoder {
@@ -84,6 +89,9 @@ private:
     bool noMore = false;
     uint8_t marker = 0xff;
     int scanN = 0, order[4] = { 0, 0, 0, 0 };
+    /* progressive files: the current scan's band and bit positions, the blocks still covered by an end-of-band run */
+    bool progressive = false;
+    int specStart = 0, specEnd = 63, succHigh = 0, succLow = 0, eobRun = 0;
 
     static bool fail(std::string& err, const char* m) { err = m; return false; }
     int get8() { return p < end ? *p++ : 0; }
@@ -132,11 +140,134 @@ private:
         return (int)(k & mask) + bias;
     }
 
-    bool decodeBlock(short data[64], Component& c)
+    int getBit()
+    {
+        if (codeBits < 1) growBuffer();
+        if (codeBits < 1) return 0;
+        const uint32_t k = codeBuffer;
+        codeBuffer <<= 1;
+        --codeBits;
+        return (int)(k >> 31);
+    }
+
+    int getBits(int n)
+    {
+        if (n == 0) return 0;
+        if (codeBits < n) growBuffer();
+        if (codeBits < n) return 0;
+        const uint32_t k = (codeBuffer << n) | (codeBuffer >> (32 - n));
+        const uint32_t mask = (1u << n) - 1u;
+        codeBuffer = k & ~mask;
+        codeBits -= n;
+        return (int)(k & mask);
+    }
+
+    static const uint8_t* zigzagTable()
     {
         static const uint8_t zigzag[64 + 15] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
                                                  63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63 };
+        return zigzag;
+    }
+
+    /* DC coefficient of one block in a progressive scan: the first scan stores the prediction sum shifted up by the
+     * scan's low bit position, a refinement scan adds one more bit (stb_image.h:2265-2292) */
+    bool decodeBlockProgDc(short data[64], Component& c)
+    {
+        if (specEnd != 0) return false;
+        if (codeBits < 16) growBuffer();
+        if (succHigh == 0) {
+            memset(data, 0, 64 * sizeof(short));
+            const int t = huffDecode(hdc[c.hd]);
+            if (t < 0 || t > 15) return false;
+            const int diff = t ? extendReceive(t) : 0;
+            const long long dc = (long long)c.dcPred + diff;
+            if (dc > 2147483647LL || dc < -2147483647LL - 1) return false;
+            c.dcPred = (int)dc;
+            const long long v = dc * (1LL << succLow);
+            if (v > 32767 || v < -32768) return false;
+            data[0] = (short)v;
+        } else if (getBit()) {
+            data[0] = (short)(data[0] + (short)(1 << succLow));
+        }
+        return true;
+    }
+
+    /* AC band of one block in a progressive scan (stb_image.h:2295-2412): first scans place new coefficients and
+     * count end-of-band runs over whole blocks; refinement scans add one bit to every coefficient that is already
+     * non-zero and place the new +-1 coefficients between them */
+    bool decodeBlockProgAc(short data[64], Component& c)
+    {
+        if (specStart == 0) return false;
+        const uint8_t* zigzag = zigzagTable();
+        const Huff& ac = hac[c.ha];
+        if (succHigh == 0) {
+            const int shift = succLow;
+            if (eobRun) { --eobRun; return true; }
+            int k = specStart;
+            do {
+                const int rs = huffDecode(ac);
+                if (rs < 0) return false;
+                const int s = rs & 15, r = rs >> 4;
+                if (s == 0) {
+                    if (r < 15) {
+                        eobRun = 1 << r;
+                        if (r) eobRun += getBits(r);
+                        --eobRun;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    const int z = zigzag[k++];
+                    data[z] = (short)(extendReceive(s) * (1 << shift));
+                }
+            } while (k <= specEnd);
+            return true;
+        }
+        const short bit = (short)(1 << succLow);
+        auto refine = [&](short* q) {
+            if (getBit())
+                if ((*q & bit) == 0) *q = (short)(*q > 0 ? *q + bit : *q - bit);
+        };
+        if (eobRun) {
+            --eobRun;
+            for (int k = specStart; k <= specEnd; ++k) {
+                short* q = &data[zigzag[k]];
+                if (*q != 0) refine(q);
+            }
+            return true;
+        }
+        int k = specStart;
+        do {
+            const int rs = huffDecode(ac);
+            if (rs < 0) return false;
+            int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (r < 15) {
+                    eobRun = (1 << r) - 1;
+                    if (r) eobRun += getBits(r);
+                    r = 64;                         /* to the end of the band */
+                }
+            } else {
+                if (s != 1) return false;
+                s = getBit() ? bit : -bit;
+            }
+            while (k <= specEnd) {
+                short* q = &data[zigzag[k++]];
+                if (*q != 0) refine(q);
+                else {
+                    if (r == 0) { *q = (short)s; break; }
+                    --r;
+                }
+            }
+        } while (k <= specEnd);
+        return true;
+    }
+
+    bool decodeBlock(short data[64], Component& c)
+    {
+        const uint8_t* zigzag = zigzagTable();
         const Huff& dc = hdc[c.hd];
         const Huff& ac = hac[c.ha];
         const uint16_t* dq = dequant[c.tq];
@@ -231,6 +362,7 @@ private:
     void resetEntropy()
     {
         codeBits = 0; codeBuffer = 0; noMore = false; marker = 0xff;
+        eobRun = 0;
         for (int i = 0; i < 4; ++i) comp[i].dcPred = 0;
     }
 
@@ -249,6 +381,34 @@ private:
         resetEntropy();
         int todo = restartInterval ? restartInterval : 0x7fffffff;
         short block[64];
+        if (progressive) {
+            if (scanN == 1) {
+                Component& c = comp[order[0]];
+                const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+                for (int j = 0; j < h; ++j)
+                    for (int i = 0; i < w; ++i) {
+                        short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.coeffW);
+                        const bool ok = specStart == 0 ? decodeBlockProgDc(data, c) : decodeBlockProgAc(data, c);
+                        if (!ok) return fail(err, "bad progressive JPEG scan");
+                        if (!restartIfDue(todo)) return true;
+                    }
+                return true;
+            }
+            for (int j = 0; j < mcusY; ++j)
+                for (int i = 0; i < mcusX; ++i) {
+                    for (int k = 0; k < scanN; ++k) {
+                        Component& c = comp[order[k]];
+                        for (int y = 0; y < c.v; ++y)
+                            for (int x = 0; x < c.h; ++x) {
+                                const int x2 = i * c.h + x, y2 = j * c.v + y;
+                                short* data = c.coeff.data() + 64 * ((size_t)x2 + (size_t)y2 * c.coeffW);
+                                if (!decodeBlockProgDc(data, c)) return fail(err, "bad progressive JPEG scan");     /* interleaved scans carry DC only */
+                            }
+                    }
+                    if (!restartIfDue(todo)) return true;
+                }
+            return true;
+        }
         if (scanN == 1) {
             Component& c = comp[order[0]];
             const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
@@ -276,6 +436,22 @@ private:
         return true;
     }
 
+    /* progressive files: dequantise and transform every block that holds pixels, once all scans are in (stb_image.h:3080-3097) */
+    void finishProgressive()
+    {
+        for (int n = 0; n < ncomp; ++n) {
+            Component& c = comp[n];
+            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+            const uint16_t* dq = dequant[c.tq];
+            for (int j = 0; j < h; ++j)
+                for (int i = 0; i < w; ++i) {
+                    short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.coeffW);
+                    for (int k = 0; k < 64; ++k) data[k] = (short)(data[k] * dq[k]);
+                    idctBlock(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                }
+        }
+    }
+
     bool parse(std::string& err)
     {
         if (end - p < 4 || p[0] != 0xff || p[1] != 0xd8) return fail(err, "not a JPEG stream");
@@ -294,8 +470,8 @@ private:
             }
             if (m == 0xd9) break;
             if (m >= 0xd0 && m <= 0xd7) continue;
-            if (m == 0xc2 || m == 0xc6 || m == 0xca || m == 0xce) return fail(err, "progressive JPEG is not supported");
-            if (m == 0xc9 || m == 0xcb || m == 0xcd || m == 0xcf) return fail(err, "arithmetic-coded JPEG is not supported");
+            if (m == 0xc3 || m == 0xc5 || m == 0xc6 || m == 0xc7) return fail(err, "lossless / differential JPEG is not supported");
+            if (m == 0xc9 || m == 0xca || m == 0xcb || m == 0xcd || m == 0xce || m == 0xcf) return fail(err, "arithmetic-coded JPEG is not supported");
             if (end - p < 2) return fail(err, "truncated JPEG");
             int len = get16() - 2;
             if (len < 0 || len > end - p) return fail(err, "bad JPEG segment length");
@@ -340,8 +516,9 @@ private:
             case 0xee:
                 if (len >= 12 && !memcmp(seg, "Adobe\0", 6)) adobeTransform = seg[11];
                 break;
-            case 0xc0: case 0xc1: {
+            case 0xc0: case 0xc1: case 0xc2: {
                 if (haveFrame || len < 6) return fail(err, "bad SOF");
+                progressive = m == 0xc2;
                 if (seg[0] != 8) return fail(err, "only 8-bit JPEG is supported");
                 height = (seg[1] << 8) | seg[2]; width = (seg[3] << 8) | seg[4]; ncomp = seg[5];
                 if (width <= 0 || height <= 0) return fail(err, "bad JPEG size");
@@ -369,6 +546,7 @@ private:
                     c.w2 = mcusX * c.h * 8;
                     c.h2 = mcusY * c.v * 8;
                     c.data.assign((size_t)c.w2 * c.h2, 0);
+                    if (progressive) { c.coeffW = c.w2 / 8; c.coeff.assign((size_t)c.w2 * c.h2, 0); }
                 }
                 haveFrame = true;
                 break;
@@ -383,10 +561,23 @@ private:
                     while (which < ncomp && comp[which].id != id) ++which;
                     if (which == ncomp) return fail(err, "bad SOS component");
                     comp[which].hd = q >> 4; comp[which].ha = q & 15;
-                    if (comp[which].hd > 3 || comp[which].ha > 3 || !hdc[comp[which].hd].built || !hac[comp[which].ha].built) return fail(err, "JPEG scan without its Huffman table");
+                    if (comp[which].hd > 3 || comp[which].ha > 3) return fail(err, "bad SOS table index");
                     order[i] = which;
                 }
-                if (seg[1 + 2 * scanN] != 0 || seg[3 + 2 * scanN] != 0) return fail(err, "bad SOS (spectral selection in a sequential file)");
+                specStart = seg[1 + 2 * scanN]; specEnd = seg[2 + 2 * scanN];
+                succHigh = seg[3 + 2 * scanN] >> 4; succLow = seg[3 + 2 * scanN] & 15;
+                if (progressive) {
+                    if (specStart > 63 || specEnd > 63 || specStart > specEnd || succHigh > 13 || succLow > 13) return fail(err, "bad SOS");
+                } else {
+                    if (specStart != 0 || succHigh != 0 || succLow != 0) return fail(err, "bad SOS (spectral selection in a sequential file)");
+                    specEnd = 63;
+                }
+                for (int i = 0; i < scanN; ++i) {
+                    /* the tables this scan reads: both in a sequential file, DC only or AC only in a progressive one */
+                    const Component& c = comp[order[i]];
+                    const bool needDc = !progressive || specStart == 0, needAc = !progressive || specStart != 0;
+                    if ((needDc && !hdc[c.hd].built) || (needAc && !hac[c.ha].built)) return fail(err, "JPEG scan without its Huffman table");
+                }
                 p = segEnd;
                 if (!decodeScan(err)) return false;
                 decoded = true;
@@ -397,6 +588,7 @@ private:
             p = segEnd;
         }
         if (!decoded) return fail(err, "JPEG without image data");
+        if (progressive) finishProgressive();
         return true;
     }
 

@@ -380,9 +380,9 @@ const char* pt_scene_log(const PtScene* s);
  * inside tinygltf, external/include/tiny_gltf.h): writes width*height*4 bytes when rgba is not NULL and
  * capacity suffices; call with rgba == NULL to learn the size. */
 int pt_decode_png(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height);
-/* The same for sequential 8-bit JPEG streams; follows stb_image's integer inverse DCT, chroma upsampling and
- * YCbCr -> RGB arithmetic (external/include/stb_image.h:2426-2524, :3465-3527, :3659-3683).  Progressive
- * files are refused. */
+/* The same for sequential and progressive 8-bit JPEG streams; follows stb_image's integer inverse DCT, chroma
+ * upsampling, YCbCr -> RGB arithmetic and progressive scan handling (external/include/stb_image.h:2265-2412,
+ * :2426-2524, :3465-3527, :3659-3683).  Arithmetic-coded files are refused, as stb_image refuses them. */
 int pt_decode_jpeg(const uint8_t* bytes, size_t n, uint8_t* rgba, size_t capacity, int* width, int* height);
 int pt_scene_add_material(PtScene* s, const PtMaterial* m);
 int pt_scene_add_texture(PtScene* s, const uint8_t* data, int w, int h, int comps);

@@ -410,7 +410,9 @@ def test_jpeg_grey_rgb_and_marker_rules(pt):
 def test_jpeg_rejects_what_it_cannot_read(pt):
     import jpeg_util as J
     data, _ = J.encode(_smooth_image(16, 16, 1))
-    with pytest.raises(pt.PtError, match="progressive"):
+    with pytest.raises(pt.PtError, match="arithmetic"):
+        pt.decode_jpeg(data.replace(b"\xff\xc0", b"\xff\xc9", 1))
+    with pytest.raises(pt.PtError):      # a sequential scan (full band) under a progressive frame header
         pt.decode_jpeg(data.replace(b"\xff\xc0", b"\xff\xc2", 1))
     for bad in (b"", b"\xff\xd8", data[:40], data[:len(data) // 2].replace(b"\xff\xda", b"\xff\xdb", 1)):
         with pytest.raises(pt.PtError):
@@ -418,6 +420,21 @@ def test_jpeg_rejects_what_it_cannot_read(pt):
     # a truncated scan still gives an image of the right size (missing blocks decode from zero bits)
     cut = pt.decode_jpeg(data[:len(data) - 40] + b"\xff\xd9")
     assert cut.shape == (16, 16, 4)
+
+
+def test_progressive_jpeg_fixtures(pt):
+    """Progressive files (tests/golden/progressive, made by libjpeg through Pillow): the pixels are the ones the
+    reference's vendored stb_image makes of them (hashes stored by tests/golden/make_progressive_jpegs.py)."""
+    import hashlib
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "progressive")
+    expected = json.load(open(os.path.join(gold, "expected.json")))
+    assert len(expected) >= 7
+    for name, e in expected.items():
+        data = open(os.path.join(gold, name + ".jpg"), "rb").read()
+        assert len(data) == e["bytes"] and b"\xff\xc2" in data
+        got = pt.decode_jpeg(data)
+        assert got.shape == (e["height"], e["width"], 4)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == e["rgba_sha256"], name
 
 
 def test_glb_with_jpeg_texture(pt, scenes, tmp_path):

@@ -209,6 +209,28 @@ def test_gltf_import_equals_reference_import_on_generated_files(pt, scenes, tmp_
         _compare_loaded(pt, pt.Scene(p), r, len(d["Materials"]))
 
 
+def test_gltf_import_equals_reference_import_with_a_progressive_jpeg_texture(pt, scenes, tmp_path):
+    """tinygltf + stb_image read progressive JPEG textures; so does the import, to the same bytes"""
+    import glb_util as G
+    data = open(os.path.join(HERE, "golden", "progressive", "rgb420_130x67_q95.jpg"), "rb").read()
+    b = G.GlbBuilder()
+    bv = b._view(data)
+    b.doc["images"].append(dict(bufferView=bv, mimeType="image/jpeg"))
+    b.doc["textures"].append(dict(source=0))
+    b.material(pbrMetallicRoughness=dict(baseColorTexture=dict(index=0)))
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.node(root=True, mesh=b.mesh([dict(attributes=dict(POSITION=b.accessor(pos, "VEC3", 5126)), material=0)]))
+    b.write_glb(tmp_path / "pj.glb")
+    d = scenes.scene_dict("cornell_orig")
+    d["Objects"].append(dict(TYPE="gltf", FILE=str(tmp_path / "pj.glb"), TRANS=[0.0, 1.0, 0.0], ROTAT=[0.0, 0.0, 0.0], SCALE=[1.0, 1.0, 1.0]))
+    p = tmp_path / "pj.json"
+    p.write_text(json.dumps(d))
+    r = ref.load_scene(str(p), pt.TRI_DTYPE)
+    sc = pt.Scene(p)
+    assert sc.log == "" and len(r["textures"]) == 1 and r["textures"][0].shape == (67, 130, 4)
+    _compare_loaded(pt, sc, r, len(d["Materials"]))
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(ref.REFERENCE, "scenes")), reason="reference scene files are not present on this machine")
 def test_every_shipped_scene_file_loads_like_the_reference(pt):
     import glob
@@ -246,6 +268,13 @@ def test_png_jpeg_hdr_decoders_equal_stb_image(pt, scenes, tmp_path):
     data, _info = J.encode(T._smooth_image(21, 30, 5)[..., 0])
     (tmp_path / "grey.jpg").write_bytes(data)
     assert pt.decode_jpeg(data).tobytes() == ref.stbi(str(tmp_path / "grey.jpg"))[2].tobytes()
+    # progressive files (libjpeg-made fixtures): DC / AC first and refinement scans, end-of-band runs, restart markers
+    gold = os.path.join(HERE, "golden", "progressive")
+    names = sorted(f for f in os.listdir(gold) if f.endswith(".jpg"))
+    assert len(names) >= 7
+    for f in names:
+        data = open(os.path.join(gold, f), "rb").read()
+        assert pt.decode_jpeg(data).tobytes() == ref.stbi(os.path.join(gold, f))[2].tobytes(), f
     # Radiance .hdr (run-length and flat scanlines) and 8-bit files as environment maps: stbi_loadf on both sides
     img = (rng.rand(6, 40, 3) ** 4 * 50).astype(np.float32)
     img[0, :20] = (0.25, 0.5, 1.0)

@@ -30,3 +30,6 @@ base = dict(Materials={"a": dict(TYPE="Diffuse", RGB=[1, 1, 1])}, Camera=scenes.
 (d / "base.json").write_text(json.dumps(base))
 PY
 "$ROOT/build/fuzz/fuzz_host" "$W/seed.glb" "$W/seed.png" "$W/seed.json" "${1:-3000}" "$W" "${2:-12345}" "$W/seed.jpg"
+# the same with progressive JPEG seeds (4:2:0 with restart markers, CMYK): refinement scans and end-of-band runs under corruption
+"$ROOT/build/fuzz/fuzz_host" "$W/seed.glb" "$W/seed.png" "$W/seed.json" "${1:-3000}" "$W" "${2:-12345}" "$ROOT/tests/golden/progressive/rgb420_8x9_q75_restart.jpg"
+"$ROOT/build/fuzz/fuzz_host" "$W/seed.glb" "$W/seed.png" "$W/seed.json" "${1:-3000}" "$W" "$((${2:-12345} + 1))" "$ROOT/tests/golden/progressive/cmyk_64x48_q75.jpg"
