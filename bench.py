@@ -361,6 +361,9 @@ def main():
         if not args.no_extras and world == 1:
             # ---- the reference-shaped call: one iteration per call of pathtrace(pbo = NULL, frame, iteration)
             n_single = 48
+            # the library's rule: four calls in flight, six / eight when the process has 8 / 16 hardware queues; PT_PIPELINE fixes it
+            hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+            calls_in_flight = int(os.environ.get("PT_PIPELINE", "0") or 0) or (8 if hwq >= 16 else 6 if hwq >= 8 else 4)
             tr.clear()
             tr.trace(1)
             tr.sync()
@@ -379,8 +382,9 @@ def main():
             extras["single_iteration"] = {"ms_per_iter": round((s1 - s0) / n_single * 1e3, 4),
                                           "Mpaths_bounce_s": round(ss.pathBounces / (s1 - s0) / 1e6, 1), "iterations": n_single,
                                           "ms_per_iter_waiting_after_every_call": round((w1 - w0) / 16 * 1e3, 4),
-                                          "path_state_bytes_in_flight": int(176 * npix) * 4,
-                                          "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end: up to four calls "
+                                          "path_state_bytes_in_flight": int(176 * npix) * calls_in_flight,
+                                          "calls_in_flight": calls_in_flight,
+                                          "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end: up to calls_in_flight calls "
                                                  "overlap on the device (a row of the path state and a stream each, accumulation in call order); "
                                                  "the second figure has a host wait after every call, nothing overlaps"}
             extras["path_state_bytes_in_flight"] = int(176 * npix) * B

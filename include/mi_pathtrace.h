@@ -237,7 +237,9 @@ int pt_destroy(PtContext* ctx);
  * per pixel, accumulated into the running-sum image.  Asynchronous: the call
  * returns before the device is done, and calls issued ahead of the device
  * overlap there (up to four iterations in flight, each on a row of the path
- * state with streams of its own; environment PT_PIPELINE=1 turns that off).
+ * state with streams of its own; six or eight when the process was started
+ * with GPU_MAX_HW_QUEUES of 8 or 16, since streams beyond the hardware queues
+ * serialise; environment PT_PIPELINE=n fixes the depth, 1 turns it off).
  * Their sums reach the image in call order, so it holds the same bits as with
  * one call at a time; every other entry point that reads the image or uses the
  * path state is ordered after all calls made before it. */
