@@ -83,22 +83,23 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 /* ------------------------------------------------------------------ camera
  * One thread per pixel: 2x2 stratified jitter cell = iter % 4, two draws from the
  * (iter, pixel, 0) stream, pinhole direction (generateRayFromCamera,
- * src/pathtrace.cu:694-745).  Threads walk the image in 8x8 tiles (a wave = one tile), so the
- * work list of the first traversal is filed tile by tile and the 64 rays a traversal wave picks
- * up together cross the same part of the scene; everything a pixel owns (RNG stream, state
- * slot) is addressed by its row-major index as before. */
+ * src/pathtrace.cu:694-745).  Threads walk the image in 8x8 tiles (a wave = one tile, a workgroup
+ * = a strip of four tiles, the grid = strips across x strips down x iterations: no division
+ * to find a pixel), so the work list of the first traversal is filed tile by tile and the 64 rays
+ * a traversal wave picks up together cross the same part of the scene; everything a pixel owns
+ * (RNG stream, state slot) is addressed by its row-major index as before. */
 __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Batch bt, int traceDepth, PathState st, Queues q, uint32_t* traceCount)
 {
     __shared__ int s_tmp[kBlock / 64 + 1];
-    st = st.at(blockIdx.y);
-    uint32_t* live = q.at(blockIdx.y).live;
-    const int iter = bt.iterBase + (int)blockIdx.y * bt.iterStride;
+    const int row = (int)blockIdx.z;
+    st = st.at(row);
+    uint32_t* live = q.at(row).live;
+    const int iter = bt.iterBase + row * bt.iterStride;
     const int W = cam.resolution[0], H = cam.resolution[1];
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    const int tilesX = (W + 7) >> 3;
-    const int tile = t >> 6, x = ((tile % tilesX) << 3) + (t & 7), y = ((tile / tilesX) << 3) + ((t >> 3) & 7);
+    const int t = threadIdx.x;
+    const int x = ((int)blockIdx.x << 5) + ((t >> 6) << 3) + (t & 7), y = ((int)blockIdx.y << 3) + ((t >> 3) & 7);
     const int index = y * W + x;
-    if (t == 0) live[0] = (uint32_t)(W * H);
+    if (t == 0 && blockIdx.x == 0 && blockIdx.y == 0) live[0] = (uint32_t)(W * H);
     bool cand = false;
     if (x < W && y < H) {
     Lcg rng;
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
     }
     }
     if (S.numBvhMeshes > 0) {
-        const int at = blockAppendIndex(cand, traceCount + blockIdx.y * kCtrStride, s_tmp);
+        const int at = blockAppendIndex(cand, traceCount + row * kCtrStride, s_tmp);
         if (at >= 0) st.traceQueue[at] = index;
     }
 }
@@ -871,8 +872,8 @@ extern "C++" {
 
 void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount)
 {
-    const long long tiles = (long long)((cam.resolution[0] + 7) / 8) * ((cam.resolution[1] + 7) / 8);
-    hipLaunchKernelGGL(k_camera, dim3(gridFor(tiles * 64), bt.count), dim3(kBlock), 0, s, S, cam, bt, depth, st, q, traceCount);
+    static_assert(kBlock == 256, "a camera workgroup is a strip of four 8x8 tiles");
+    hipLaunchKernelGGL(k_camera, dim3((cam.resolution[0] + 31) / 32, (cam.resolution[1] + 7) / 8, bt.count), dim3(kBlock), 0, s, S, cam, bt, depth, st, q, traceCount);
 }
 /* grid of the light one-thread-per-slot kernels: all rows together about 16k workgroups (see PT_FOR_VIRTUAL_BLOCKS) */
 static inline dim3 slotGrid(const Queues& q, const Batch& bt)
