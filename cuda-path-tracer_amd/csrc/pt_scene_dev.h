@@ -309,7 +309,10 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
 {
     tv.lo = mulMV(g.I, r.o, 1.0f);
     tv.ld = normalize(mulMV(g.I, r.d, 0.0f));
-    tv.invDir = 1.0f / tv.ld;
+    /* reciprocal for the walked boxes only, which carry a slack of 2^-15: the hardware's one-ulp approximation (one
+     * instruction per component instead of an IEEE division) is far inside it; the check of a hit against its host
+     * leaf box takes the true quotient (passesHostLeafBox) */
+    tv.invDir = f3(__builtin_amdgcn_rcpf(tv.ld.x), __builtin_amdgcn_rcpf(tv.ld.y), __builtin_amdgcn_rcpf(tv.ld.z));
     tv.closestT = 3.402823466e+38f;
     tv.best = -1;
     tv.bestRank = 0x7fffffff;
