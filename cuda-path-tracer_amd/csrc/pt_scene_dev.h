@@ -656,7 +656,8 @@ PT_DEV bool failsRootNode(const SceneView& S, const DGeom& g, const Ray& r)
  * and the min/max ignore a NaN operand, so odd rays are kept — then, for rays that pass it, the mesh's root node. */
 PT_DEV bool mayHitBvhMeshes(const SceneView& S, const Ray& r, float maxDist, bool rootTest = false)
 {
-    const F3 inv = 1.0f / r.d;
+    /* the box is padded by a percent of its size: the hardware's one-ulp reciprocal is exact enough */
+    const F3 inv = f3(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
     for (int i = 0; i < S.numGeoms; ++i) {
         const DGeom& g = S.geoms[i];
         if (!isBvhMesh(S, g)) continue;
