@@ -163,17 +163,18 @@ def test_bvh_closest_hit_equals_brute_force(pt, scenes, orc):
 
 
 def test_device_bvh_layout_is_valid_and_tighter_than_the_host_topology(pt, scenes):
-    """The 4-wide hierarchy the device walks, built over boxes around single triangles (the host BVH's leaves only
-    decide which hits count): every triangle referenced once, one leaf per triangle, child boxes hold what is below
-    them, ranks are a permutation; its summed relative node area (the SAH measure of expected box tests) is not worse
-    than the host topology's although it holds 4 children per node and goes four times as deep in leaves."""
+    """The 4-wide hierarchy the device walks, built over boxes around single triangles, sibling pairs of which share
+    a leaf (the host BVH's leaves only decide which hits count): every triangle referenced once, one or two triangles
+    per leaf, child boxes hold what is below them, ranks are a permutation; its summed relative node area (the SAH
+    measure of expected box tests) is not worse than the host topology's although it holds 4 children per node and
+    goes far deeper in leaves."""
     for tris in (scenes.blob_mesh(64, 65, 3, ((0, 0, 0), (0, 0, 0), (1, 1, 1)), [0, 1], bumps=8, amplitude=0.4),
                  scenes.cube_mesh(((0, 0, 0), (0, 0, 0), (1, 1, 1)), 0),
                  scenes.blob_mesh(9, 7, 4, ((1, 2, 3), (10, 20, 30), (2, 1, 0.5)), [0])):
         st = pt.bvh_device_layout(tris)
         _, _, host = pt.bvh_build(tris)
         assert st.trianglesReferenced == len(tris)
-        assert st.leaves == len(tris) and st.leaves >= host["leaves"]
+        assert (len(tris) + 1) // 2 <= st.leaves <= len(tris) and st.leaves >= host["leaves"]
         assert 1 <= st.wideDepth <= host["max_depth"] + 1
         assert st.wideNodes >= 1
         assert st.sahCostDevice <= st.sahCostHost * 1.05 + 1.0
