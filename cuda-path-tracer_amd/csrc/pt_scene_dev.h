@@ -281,7 +281,7 @@ PT_DEV float hitTriangleRec(float4 a, float4 b, float4 c, F3 lo, F3 ld, F3& bary
  * (subtraction and multiplication by the same 1/d are monotone), so a ray that passes a leaf
  * box passes every ancestor.  The leaf boxes therefore are a FILTER on triangle hits, and the
  * hierarchy that is walked to find those hits is free.  This traversal walks its own: 4-wide
- * nodes down to boxes around single triangles, nearest child first, entry distance kept on
+ * nodes down to boxes around one or two triangles, nearest child first, entry distance kept on
  * the stack for pruning at pop time, boxes that only have to be conservative (kBoxSlack).  A
  * closest hit is checked against the box of its leaf in the reference's BVH, with the
  * reference's arithmetic (passesHostLeafBox), and the reference's choice among equals is

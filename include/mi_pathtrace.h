@@ -325,13 +325,13 @@ void pt_bvh_free(PtBvh* b);
 /* The device layout pt_create derives from a host BVH (src/bvh.h:55-65 nodes + index array): every
  * triangle keeps the box of its leaf in the host BVH (which decides whether a hit on it counts) and its
  * rank in the reference's visiting order; the hierarchy that is walked is built over boxes around
- * single triangles and stored as 4-wide nodes.  This runs the same code on the host only (no GPU) and
+ * single triangles (two that end up as siblings share a leaf) and stored as 4-wide nodes.  This runs the same code on the host only (no GPU) and
  * checks the result: every triangle is referenced exactly once, every child box holds what is below
  * it, visit ranks are a permutation.  Returns PT_OK or PT_EINVAL with pt_last_error() naming the violation. */
 typedef struct PtLayoutStats {
     int32_t wideNodes;           /* 4-wide nodes                                      */
     int32_t wideDepth;           /* levels of 4-wide nodes                            */
-    int32_t leaves;              /* leaf references of the walked hierarchy (one per triangle) */
+    int32_t leaves;              /* leaf references of the walked hierarchy (one or two triangles each) */
     int32_t trianglesReferenced;
     float sahCostHost;           /* sum over inner nodes of area(node)/area(root): host topology */
     float sahCostDevice;         /* the same measure for the 4-wide hierarchy         */
