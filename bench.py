@@ -186,11 +186,11 @@ def main():
             torch.cuda.synchronize()
 
     # iterations per launch group: every kernel launch ends with the few longest rays of its bounce, a cost per launch
-    # and not per iteration, so groups are as large as 210 GB of path state (about 190 B per pixel and iteration) allow,
+    # and not per iteration, so groups are as large as 210 GB of path state (about 195 B per pixel and iteration) allow,
     # in powers of two so that the persistent traversal grid divides evenly over the rows
     budget = min(210e9, 0.8 * torch.cuda.mem_get_info()[0])       # never more than four fifths of what is free now
     per_step = per_rank_iterations(args.scaling, world, args.spp_per_step, args.total_spp)
-    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 190.0 * b <= budget)
+    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 195.0 * b <= budget)
     if args.scaling == "strong":
         B = min(B, per_step)
     B = max(1, min(B, 512))
@@ -382,12 +382,12 @@ def main():
             extras["single_iteration"] = {"ms_per_iter": round((s1 - s0) / n_single * 1e3, 4),
                                           "Mpaths_bounce_s": round(ss.pathBounces / (s1 - s0) / 1e6, 1), "iterations": n_single,
                                           "ms_per_iter_waiting_after_every_call": round((w1 - w0) / 16 * 1e3, 4),
-                                          "path_state_bytes_in_flight": int(176 * npix) * calls_in_flight,
+                                          "path_state_bytes_in_flight": int(192 * npix) * calls_in_flight,
                                           "calls_in_flight": calls_in_flight,
                                           "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end: up to calls_in_flight calls "
                                                  "overlap on the device (a row of the path state and a stream each, accumulation in call order); "
                                                  "the second figure has a host wait after every call, nothing overlaps"}
-            extras["path_state_bytes_in_flight"] = int(176 * npix) * B
+            extras["path_state_bytes_in_flight"] = int(192 * npix) * B
             if st.launchesTrace > 0:
                 extras["ray_sets"] = _ray_sets(pt, tr, npix)
 

@@ -184,7 +184,7 @@ int batchAlloc(std::vector<void*>& owned, T** out, size_t count, bool zero)
 }
 
 /* path state, queues and per-iteration contribution buffers for `batch` iterations in flight
- * (about 176 bytes per pixel and iteration).  The new buffers replace the old ones only when every allocation
+ * (about 192 bytes per pixel and iteration).  The new buffers replace the old ones only when every allocation
  * has succeeded; after a failure the context still holds, and keeps using, the state it had.  Path state at the
  * largest group sizes takes most of the device, so the old buffers are released first when the new ones would not
  * fit beside them — in that case a failure leaves the context without path state (batch 0), every entry point that
@@ -193,7 +193,7 @@ int allocBatchState(PtContext* c, int batch)
 {
     const size_t N = (size_t)c->numPixels, B = (size_t)batch;
     size_t freeB = 0, totalB = 0;
-    const size_t need = N * B * 190;
+    const size_t need = N * B * 195;
     const bool known = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
     if (known && need > totalB) {       /* cannot fit on this device at all: fail before anything is released */
         pt_set_error("path state for %d iterations at %d pixels needs about %zu MB, the device has %zu MB", batch, c->numPixels, need >> 20, totalB >> 20);
@@ -215,8 +215,19 @@ int allocBatchState(PtContext* c, int batch)
     Q.numBlocks = (int)((N + kBlock - 1) / kBlock);
     int rc = PT_OK;
 #define BA(ptr, count, zero) if (rc == PT_OK) rc = batchAlloc(owned, &(ptr), (count), (zero))
-    BA(P.rayO, N * B, false); BA(P.rayD, N * B, false); BA(P.col, N * B, false);
-    BA(P.hitA, N * B, false); BA(P.hitB, N * B, false); BA(P.hitTri, N * B, false);
+    if (kRecStride == 1) {
+        BA(P.rayO.p, N * B, false); BA(P.rayD.p, N * B, false); BA(P.col.p, N * B, false); BA(P.hitA.p, N * B, false);
+        P.rayD0 = P.rayD.p; P.hitA0 = P.hitA.p;
+    } else {
+        /* one aligned 64-byte record per path: origin, direction, colour, first half of the hit record */
+        static_assert(kRecStride == 1 || kRecStride == 4, "path records are separate arrays or one 64-byte record per path");
+        float4* block = nullptr;
+        BA(block, N * B * 4, false);
+        P.rayO.p = block; P.rayD.p = block + 1; P.col.p = block + 2; P.hitA.p = block + 3;
+        BA(P.rayD0, N * B, false); BA(P.hitA0, N * B, false);
+    }
+    BA(P.hitB, N * B, false);
+    BA(P.hitTri, N * B, false);
     BA(P.shRec, N * B * 3, false); BA(P.traceQueue, N * B, false);
     BA(P.image, N * B * 3, true);
     BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);

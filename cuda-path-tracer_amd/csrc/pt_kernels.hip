@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
         Ray r; r.o = f3(cam.position); r.d = dir;
         cand = mayHitBvhMeshes(S, r, __builtin_inff(), true);
     }
-    st.rayD[index] = make_float4(dir.x, dir.y, dir.z, __int_as_float(cand ? 1 : 0));
+    const float4 dRec = make_float4(dir.x, dir.y, dir.z, __int_as_float(cand ? 1 : 0));
+    if (S.cameraOrigin) st.rayD0[index] = dRec;
+    else st.rayD[index] = dRec;
     if (!S.cameraOrigin) {      /* otherwise bounce 0 takes these from the scene view (loadRayO / loadCol) */
         st.rayO[index] = make_float4(cam.position[0], cam.position[1], cam.position[2], __int_as_float(0));
         st.col[index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(traceDepth));
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     trav = true;
                     fetch = false;
                 } else if (MODE == TRACE_CLOSEST) {
-                    st.hitA[pix] = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(best.tri));
+                    hitARef(S, st, pix, bounce) = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(best.tri));
                     if (best.t > 0.0f) st.hitTri[pix] = best.geom;
                 } else {
                     /* settle the path colour, then the image add the shade stage held back */
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                         fetch = false;
                         if (MODE == TRACE_CLOSEST) {
                             pix = st.traceQueue[sidx];
-                            float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix];
+                            float4 o = loadRayO(S, st.rayO, pix, bounce), d = loadRayD(S, st, pix, bounce);
                             r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
                             best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
                         } else {
@@ -414,13 +416,13 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
         int key = 0;
         if (active) {
             const int pix = bounce == 0 ? slot : q.q0[slot];
-            float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix];
+            float4 o = loadRayO(S, st.rayO, pix, bounce), d = loadRayD(S, st, pix, bounce);
             Ray r; r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
             Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
             const bool traced = S.numBvhMeshes > 0 && __float_as_int(d.w) != 0;      /* the ray was filed for traversal */
             if (traced) {
                 /* the traversal left (distance, barycentric u, v, leaf-order triangle) and the geom: finish the hit */
-                float4 ha = st.hitA[pix];
+                float4 ha = hitARef(S, st, pix, bounce);
                 if (ha.x > 0.0f) {
                     const int geom = st.hitTri[pix];
                     best.t = ha.x; best.geom = geom;
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
              * the shade stage knows the misses by their place in the sorted order */
             const bool hit = best.t > 0.0f;
             if (hit || !S.leanHits || (!traced && !sortOn)) {
-                st.hitA[pix] = make_float4(best.t, best.n.x, best.n.y, best.n.z);
+                hitARef(S, st, pix, bounce) = make_float4(best.t, best.n.x, best.n.y, best.n.z);
                 if (hit || !S.leanHits) {
                     st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
                     st.hitTri[pix] = best.tri;
@@ -600,9 +602,9 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
         bool cand = false;
         if (active) {
             pix = (!sortOn && bounce == 0) ? slot : queue[slot];
-            float4 o = loadRayO(S, st.rayO, pix, bounce), d = st.rayD[pix], c = loadCol(S, st.col, pix, bounce);
+            float4 o = loadRayO(S, st.rayO, pix, bounce), d = loadRayD(S, st, pix, bounce), c = loadCol(S, st.col, pix, bounce);
             float4 ha = make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
-            if ((uint32_t)slot < missStart) ha = st.hitA[pix];
+            if ((uint32_t)slot < missStart) ha = hitARef(S, st, pix, bounce);
             float4 hb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (ha.x > 0.0f) hb = st.hitB[pix];        /* material and uv only matter for a hit */
             Path p;

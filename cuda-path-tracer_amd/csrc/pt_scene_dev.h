@@ -95,13 +95,31 @@ struct SceneView {
     float camPos[3];
 };
 
+/* Four of the 16-byte records of a path — ray origin, ray direction, colour, first half of the hit record — are
+ * addressed through this accessor: record i of a field lives at p[i * kRecStride].  Stride 1 is one array per field;
+ * stride 4 with the base pointers one record apart puts the four into one aligned 64-byte record, so a stage that
+ * reaches a path through a queue (traversal, primitives of later bounces, shading) touches one record per path instead
+ * of one line per field.  Bounce 0 walks the image in pixel order and needs only the direction: the camera kernel
+ * writes that into an array of its own (PathState::rayD0) which the stages of bounce 0 read, and they exchange the
+ * first half of the hit record through another (hitA0).  The second half of the hit record (material, uv, geom: hits
+ * only) stays an array of its own. */
+#ifndef PT_REC_STRIDE
+#define PT_REC_STRIDE 4
+#endif
+constexpr int kRecStride = PT_REC_STRIDE;
+struct PathField {
+    float4* p;
+    PT_DEV float4& operator[](size_t i) const { return p[i * kRecStride]; }
+    __host__ PT_DEV PathField& operator+=(size_t records) { p += records * kRecStride; return *this; }
+};
+
 /* origin record (xyz, previous-bounce-was-specular flag) and colour record (throughput, remaining bounces) of a path */
-PT_DEV float4 loadRayO(const SceneView& S, const float4* rayO, int pix, int bounce)
+PT_DEV float4 loadRayO(const SceneView& S, const PathField& rayO, int pix, int bounce)
 {
     if (bounce == 0 && S.cameraOrigin) return make_float4(S.camPos[0], S.camPos[1], S.camPos[2], __int_as_float(0));
     return rayO[pix];
 }
-PT_DEV float4 loadCol(const SceneView& S, const float4* col, int pix, int bounce)
+PT_DEV float4 loadCol(const SceneView& S, const PathField& col, int pix, int bounce)
 {
     if (bounce == 0 && S.cameraOrigin) return make_float4(1.0f, 1.0f, 1.0f, __int_as_float(S.traceDepth));
     return col[pix];
@@ -111,11 +129,13 @@ PT_DEV float4 loadCol(const SceneView& S, const float4* col, int pix, int bounce
  * Every iteration owns a full copy of the path state and of the queues, so slot numbering, sort
  * and compaction stay per iteration; at(k) selects iteration k's copy. */
 struct PathState {
-    float4* rayO;
-    float4* rayD;
-    float4* col;
-    float4* hitA;
+    PathField rayO;
+    PathField rayD;
+    PathField col;
+    PathField hitA;
     float4* hitB;
+    float4* rayD0;                  /* directions of the primary rays, one array in pixel order (the rayD array itself at stride 1) */
+    float4* hitA0;                  /* first half of the hit records of bounce 0, likewise */
     float* image;                   /* W*H*3: this iteration's contribution inside the kernels */
     int* hitTri;                    /* mesh-local triangle of the hit (parity hook) */
     /* shadow rays whose mesh part is still to be traced, in arrival order, three records each: (origin, max distance)
@@ -130,11 +150,25 @@ struct PathState {
     {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
-        r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.image += 3 * off;
+        r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.rayD0 += off; r.hitA0 += off; r.image += 3 * off;
         r.hitTri += off; r.shRec += 3 * off; r.traceQueue += off;
         return r;
     }
 };
+
+/* direction record (xyz, "may hit a BVH mesh" flag) of a path entering `bounce` */
+PT_DEV float4 loadRayD(const SceneView& S, const PathState& st, int pix, int bounce)
+{
+    if (bounce == 0 && S.cameraOrigin) return st.rayD0[pix];
+    return st.rayD[pix];
+}
+
+/* first half of the hit record (distance; barycentrics + triangle after the traversal, normal after the primitive stage) */
+PT_DEV float4& hitARef(const SceneView& S, const PathState& st, int pix, int bounce)
+{
+    if (bounce == 0 && S.cameraOrigin) return st.hitA0[pix];
+    return st.hitA[pix];
+}
 
 struct Queues {
     int* q0;            /* compacted queue (input of a bounce)                          */
