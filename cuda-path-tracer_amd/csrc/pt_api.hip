@@ -1184,6 +1184,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     V.envTotalPower = totalPower;
     V.numBuckets = d->materialCount + 1;
     V.numBvhMeshes = c->bvhMeshGeoms;
+    V.packGeom = d->geomCount <= 32 ? 1 : 0;
 
     /* ---- running sum, path state and queues */
     const size_t N = (size_t)c->numPixels;

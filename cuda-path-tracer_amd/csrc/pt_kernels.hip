@@ -281,8 +281,9 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     trav = true;
                     fetch = false;
                 } else if (MODE == TRACE_CLOSEST) {
-                    hitARef(S, st, pix, bounce) = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(best.tri));
-                    if (best.t > 0.0f) st.hitTri[pix] = best.geom;
+                    const int triWord = S.packGeom ? (best.tri | (best.geom << 26)) : best.tri;
+                    hitARef(S, st, pix, bounce) = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(triWord));
+                    if (!S.packGeom && best.t > 0.0f) st.hitTri[pix] = best.geom;
                 } else {
                     /* settle the path colour, then the image add the shade stage held back */
                     float4 c = st.col[pix];
@@ -424,9 +425,11 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
                 /* the traversal left (distance, barycentric u, v, leaf-order triangle) and the geom: finish the hit */
                 float4 ha = hitARef(S, st, pix, bounce);
                 if (ha.x > 0.0f) {
-                    const int geom = st.hitTri[pix];
+                    const int triWord = __float_as_int(ha.w);
+                    const int geom = S.packGeom ? ((triWord >> 26) & 31) : st.hitTri[pix];
+                    const int leafTri = S.packGeom ? (triWord & 0x3ffffff) : triWord;
                     best.t = ha.x; best.geom = geom;
-                    meshHitAttributes(S, S.geoms[geom], r.d, __float_as_int(ha.w), ha.y, ha.z, best.n, best.uv, best.mat, best.tri);
+                    meshHitAttributes(S, S.geoms[geom], r.d, leafTri, ha.y, ha.z, best.n, best.uv, best.mat, best.tri, !S.leanHits);
                 }
             }
             foldInlineGeoms<COUNT>(S, r, best, cnt);
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
                 hitARef(S, st, pix, bounce) = make_float4(best.t, best.n.x, best.n.y, best.n.z);
                 if (hit || !S.leanHits) {
                     st.hitB[pix] = make_float4(__int_as_float(best.mat), best.uv.x, best.uv.y, __int_as_float(best.geom));
-                    st.hitTri[pix] = best.tri;
+                    if (!S.leanHits) st.hitTri[pix] = best.tri;        /* read by the stage hooks only */
                 }
             }
             /* sort key: material id, misses last (INT_MAX in the reference, src/pathtrace.cu:2427-2429) */

@@ -91,6 +91,10 @@ struct SceneView {
      * of a miss record and the later stages do not read the rest (set while tracing; the stage hooks export whole
      * records and leave it off). */
     int leanHits;
+    /* With at most 32 geoms the traversal hands the geom of a mesh hit to the primitive stage in the five bits above the
+     * 26-bit leaf-order triangle index of the hit record instead of a 4-byte array entry of its own (a scattered
+     * write and a gathered read per mesh hit). */
+    int packGeom;
     int traceDepth;
     float camPos[3];
 };
@@ -567,7 +571,7 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
  * barycentrics (1 - u - v, u, v).  The closest-hit traversal only records (distance, u, v, best, geom); the
  * one-thread-per-slot stage that follows calls this, with every lane busy, for the hits that survive. */
 PT_DEV void meshHitAttributes(const SceneView& S, const DGeom& g, F3 rayD, int best, float bu, float bv,
-                              F3& N, F2& uv, int& mat, int& triOrig)
+                              F3& N, F2& uv, int& mat, int& triOrig, bool wantOrig = true)
 {
     const float bw = 1.0f - bu - bv;            /* as the triangle test forms it */
     const float4* cold = S.triCold + 4 * (size_t)(g.triStart + best);
@@ -577,7 +581,9 @@ PT_DEV void meshHitAttributes(const SceneView& S, const DGeom& g, F3 rayD, int b
     uv.x = (bw * c2.y + bu * c2.w) + bv * c3.y;
     uv.y = (bw * c2.z + bu * c3.x) + bv * c3.z;
     mat = __float_as_int(c3.w);
-    triOrig = __float_as_int(S.triHot[3 * ((size_t)g.triStart + (size_t)best) + 2].y);
+    /* the original index is wanted by the stage hooks only; inside the loop nobody reads it, and fetching it would
+     * touch one more memory line per mesh hit */
+    triOrig = wantOrig ? __float_as_int(S.triHot[3 * ((size_t)g.triStart + (size_t)best) + 2].y) : -1;
     N = normalize(mulMV(g.IT, ln, 0.0f));
     bool outside = dot(rayD, N) < 0.0f;
     if (!outside) N = -N;

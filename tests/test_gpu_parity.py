@@ -846,3 +846,34 @@ def test_cube_sphere_edge_rays_bit_exact(pt, scenes, orc, gpu_ok, tmp_path):
         tr.trace(it); o2.trace(it)
     assert _same_bits(tr.image(), o2.image())
     assert tr.stats().pathBounces == o2.stats().pathBounces
+
+
+def test_many_geoms_and_a_mesh_bit_exact(pt, scenes, orc, gpu_ok, tmp_path):
+    """More than 32 geoms: the traversal hands the geom of a mesh hit to the primitive stage through the array entry
+    instead of the spare bits of the hit record.  Closest hits and whole iterations against the oracle."""
+    d = scenes.scene_dict("cornell_orig")
+    rng = np.random.RandomState(12)
+    for k in range(36):
+        c = rng.uniform([-4, 1, -4], [4, 9, 4])
+        d["Objects"].append(dict(TYPE="sphere" if k % 2 else "cube", MATERIAL="diffuse_white", TRANS=[float(v) for v in c],
+                                 ROTAT=[float(v) for v in rng.uniform(0, 90, 3)], SCALE=[0.5, 0.4, 0.6]))
+    path = tmp_path / "many.json"
+    path.write_text(json.dumps(d))
+    sc = pt.Scene(path)
+    sc.set_resolution(64, 48)
+    ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    m = sc.add_material(type=pt.PT_PBR, color=[0.8, 0.5, 0.3], roughness=0.4, metallic=0.0, indexOfRefraction=1.5)
+    blob = scenes.blob_mesh(24, 25, 5, ident, [0], radius=2.0, center=(0.0, 4.0, 0.0))
+    blob["materialId"] = m
+    sc.add_mesh(blob)
+    assert sc.desc.contents.geomCount > 32
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    ro, rd = _ray_set(21, 20000)
+    g, ob = tr.intersect(ro, rd), o.intersect(ro, rd)
+    _hits_equal(g, ob)
+    assert (ob["triangle"] >= 0).sum() > 500
+    for it in (1, 2, 3):
+        tr.trace(it); o.trace(it)
+    assert _same_bits(tr.image(), o.image())
+    assert tr.stats().pathBounces == o.stats().pathBounces
