@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("MI_PATHTRACE_LIB") or os.path.join(_HERE, "csrc", "li
 
 PT_SPHERE, PT_CUBE, PT_GLTF_MESH = 0, 1, 2
 PT_DIFFUSE, PT_SPECULAR, PT_REFRACTIVE, PT_PBR, PT_EMITTING = 0, 1, 2, 3, 4
-PT_OPT_MATERIAL_SORT, PT_OPT_USE_BVH, PT_OPT_STAGE_TIMING, PT_OPT_COUNTERS, PT_OPT_USE_GRAPH, PT_OPT_BATCH = 1, 2, 3, 4, 5, 6
+PT_OPT_MATERIAL_SORT, PT_OPT_USE_BVH, PT_OPT_STAGE_TIMING, PT_OPT_COUNTERS, PT_OPT_USE_GRAPH, PT_OPT_BATCH, PT_OPT_LAUNCH_STREAMS = 1, 2, 3, 4, 5, 6, 7
 PT_MAX_DEPTH = 64
 PT_NOALLOC_MAX_RAYS = 262144
 
@@ -137,6 +137,7 @@ def _load():
         "pt_math_eval": (ip, [ip, ip, vp, vp, ip, vp]),
         "pt_last_error": (C.c_char_p, []),
         "pt_version": (C.c_char_p, []),
+        "pt_resource_calls": (C.c_ulonglong, []),
         "pt_bvh_build": (ip, [vp, ip, ip, C.POINTER(vp)]),
         "pt_bvh_nodes": (vp, [vp, C.POINTER(ip)]),
         "pt_bvh_indices": (vp, [vp, C.POINTER(ip)]),

@@ -161,6 +161,7 @@ struct View {
     const uint8_t* base = nullptr;
     size_t stride = 0, count = 0;
     int componentType = 0, comps = 0;
+    size_t ignoredByteStride = 0;      /* the view's byteStride when it differs from the element size (it is not followed) */
 };
 
 bool accessorView(const Doc& d, int index, View& v, std::string& err)
@@ -186,6 +187,8 @@ bool accessorView(const Doc& d, int index, View& v, std::string& err)
     /* elements are read tightly packed from the accessor's start whatever the view's byteStride says: the reference
      * indexes positions[i * 3], normals[i * 3], texcoords[i * 2] and indices[i] directly (src/scene.cpp:363-420) */
     v.stride = elem;
+    const size_t declared = (size_t)numOr(bv, "byteStride", 0);
+    v.ignoredByteStride = (declared != 0 && declared != elem) ? declared : 0;
     size_t off = (size_t)numOr(bv, "byteOffset", 0) + (size_t)numOr(a, "byteOffset", 0);
     const auto& buf = d.buffers[bi];
     if (v.count && (v.stride < elem || off > buf.size() || (v.count - 1) * v.stride + elem > buf.size() - off)) { err = "accessor reaches past its buffer"; return false; }
@@ -405,14 +408,23 @@ bool load(const std::string& path, const ptx::Mat4& root, int materialBase, int 
                 View pos, nrm, uv, idx;
                 bool haveN = false, haveUV = false, haveIdx = false;
                 if (!accessorView(d, intOr(*attrs, "POSITION", -1), pos, err)) { ok = false; return; }
+                /* an interleaved file comes out as the reference imports it — scrambled; say so, so that a caller can see why */
+                auto strideNote = [&](const View& vw, const char* what) {
+                    if (vw.ignoredByteStride)
+                        out.warnings.push_back(std::string(what) + " accessor: buffer view byteStride " + std::to_string(vw.ignoredByteStride) +
+                                               " is ignored, elements are read tightly packed as the reference reads them (src/scene.cpp:363-420); an interleaved file imports as wrong geometry");
+                };
+                strideNote(pos, "POSITION");
                 if (pos.componentType != 5126 || pos.comps != 3) { ok = false; err = "POSITION must be float VEC3"; return; }
                 if (attrs->contains("NORMAL")) {
                     if (!accessorView(d, intOr(*attrs, "NORMAL", -1), nrm, err)) { ok = false; return; }
+                    strideNote(nrm, "NORMAL");
                     if (nrm.componentType != 5126 || nrm.comps != 3) { ok = false; err = "NORMAL must be float VEC3"; return; }
                     haveN = true;
                 }
                 if (attrs->contains("TEXCOORD_0")) {
                     if (!accessorView(d, intOr(*attrs, "TEXCOORD_0", -1), uv, err)) { ok = false; return; }
+                    strideNote(uv, "TEXCOORD_0");
                     if (uv.componentType != 5126 || uv.comps != 2) { ok = false; err = "TEXCOORD_0 must be float VEC2"; return; }
                     haveUV = true;
                 }

@@ -18,9 +18,29 @@
 #include <limits>
 #include <vector>
 
+#include <atomic>
+
 using namespace ptd;
 
 void pt_set_error(const char* fmt, ...);
+
+/* Every call of this file that creates or releases a device-side resource — memory, pinned host memory, events, streams —
+ * is counted (pt_resource_calls), so that a caller, or a test, can see that an entry point which promises to allocate
+ * nothing made none.  The macros name the runtime functions they wrap; a macro is not expanded inside its own
+ * expansion, so the inner name is the runtime's. */
+static std::atomic<unsigned long long> g_resourceCalls{0};
+#define hipMalloc(...) (++g_resourceCalls, hipMalloc(__VA_ARGS__))
+#define hipFree(...) (++g_resourceCalls, hipFree(__VA_ARGS__))
+#define hipHostMalloc(...) (++g_resourceCalls, hipHostMalloc(__VA_ARGS__))
+#define hipHostFree(...) (++g_resourceCalls, hipHostFree(__VA_ARGS__))
+#define hipHostRegister(...) (++g_resourceCalls, hipHostRegister(__VA_ARGS__))
+#define hipHostUnregister(...) (++g_resourceCalls, hipHostUnregister(__VA_ARGS__))
+#define hipEventCreate(...) (++g_resourceCalls, hipEventCreate(__VA_ARGS__))
+#define hipEventCreateWithFlags(...) (++g_resourceCalls, hipEventCreateWithFlags(__VA_ARGS__))
+#define hipEventDestroy(...) (++g_resourceCalls, hipEventDestroy(__VA_ARGS__))
+#define hipStreamCreateWithFlags(...) (++g_resourceCalls, hipStreamCreateWithFlags(__VA_ARGS__))
+#define hipStreamCreateWithPriority(...) (++g_resourceCalls, hipStreamCreateWithPriority(__VA_ARGS__))
+#define hipStreamDestroy(...) (++g_resourceCalls, hipStreamDestroy(__VA_ARGS__))
 
 void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount);
 void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount);
@@ -979,6 +999,11 @@ int pt_destroy(PtContext* c)
 {
     if (!c) return PT_OK;
     (void)hipSetDevice(c->device);
+    /* kernels of a call that failed half-way may still run on a row's streams without having been joined to the main one */
+    for (int g = 0; g < kMaxStreamGroups; ++g) {
+        if (c->groupStreams[g]) (void)hipStreamSynchronize(c->groupStreams[g]);
+        if (c->shadowStreams[g]) (void)hipStreamSynchronize(c->shadowStreams[g]);
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     resolveSpans(c);
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
@@ -1209,7 +1234,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     return PT_OK;
 }
 
-static int traceBatch(PtContext* c, Batch bt)
+static int traceBatchLaunch(PtContext* c, Batch bt)
 {
     if (c->batch < 1 || bt.count < 1 || bt.count > c->batch) { pt_set_error("pt_trace: no path state for a group of %d iterations (allocated: %d)", bt.count, c->batch); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
@@ -1377,6 +1402,26 @@ static int traceBatch(PtContext* c, Batch bt)
     return PT_OK;
 }
 
+/* A launch sequence that failed half-way leaves kernels on a row's streams that were never joined to the main stream,
+ * and the bookkeeping of the pipelined rows half advanced: wait for everything the context has in flight and start the
+ * rows afresh, so that a later pt_sync / pt_destroy / allocation cannot overtake work that still uses the path state. */
+static int traceBatch(PtContext* c, Batch bt)
+{
+    const int rc = traceBatchLaunch(c, bt);
+    if (rc != PT_OK && c->stream) {
+        for (int g = 0; g < kMaxStreamGroups; ++g) {
+            if (c->groupStreams[g]) (void)hipStreamSynchronize(c->groupStreams[g]);
+            if (c->shadowStreams[g]) (void)hipStreamSynchronize(c->shadowStreams[g]);
+            c->slotBusy[g] = false;
+        }
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        c->pipeLast = -1;
+        c->pipeBarrier = true;
+    }
+    return rc;
+}
+
 int pt_trace(PtContext* c, int iter)
 {
     if (!c) { pt_set_error("pt_trace: null context"); return PT_EINVAL; }
@@ -1473,6 +1518,12 @@ int pt_set_option(PtContext* c, int option, int value)
         if (value != c->batch) { rc = allocBatchState(c, value); if (rc != PT_OK) return rc; }
         break;
     }
+    case PT_OPT_LAUNCH_STREAMS:
+        if (value < 0 || value > kMaxStreamGroups) { pt_set_error("pt_set_option: launch streams must be in [0,%d]", kMaxStreamGroups); return PT_ELIMIT; }
+        c->streamsFixed = value > 0;
+        c->streamGroups = value > 0 ? value : kDefaultStreamGroups;
+        if (value == 0) { c->tuneStage = 0; c->tuneChoice = 1; }
+        break;
     default: pt_set_error("pt_set_option: unknown option %d", option); return PT_EINVAL;
     }
     return PT_OK;
@@ -1533,6 +1584,8 @@ int pt_reset_stats(PtContext* c)
 }
 
 void* pt_stream(PtContext* c) { return c ? (void*)c->stream : nullptr; }
+
+unsigned long long pt_resource_calls(void) { return g_resourceCalls.load(); }
 
 /* the fixed-ray-set hook over staging buffers the caller of this helper owns: rays go through the production
  * intersect stage in chunks of at most `chunk` (<= one image's worth of paths) */
@@ -1696,15 +1749,21 @@ int pt_math_eval(int device, int fn, const float* a, const float* b, int n, floa
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(device));
     float *dA = nullptr, *dB = nullptr, *dR = nullptr;
-    HIP_TRY(hipMalloc((void**)&dA, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&dR, (size_t)n * 4));
-    if (b) HIP_TRY(hipMalloc((void**)&dB, (size_t)n * 4));
-    HIP_TRY(hipMemcpy(dA, a, (size_t)n * 4, hipMemcpyHostToDevice));
-    if (b) HIP_TRY(hipMemcpy(dB, b, (size_t)n * 4, hipMemcpyHostToDevice));
-    ptl_math(nullptr, fn, dA, dB, n, dR);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dR, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dA); (void)hipFree(dR); if (dB) (void)hipFree(dB);
+    /* every exit frees what was allocated */
+    hipError_t e = hipMalloc((void**)&dA, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dR, (size_t)n * 4);
+    if (e == hipSuccess && b) e = hipMalloc((void**)&dB, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(dA, a, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(dB, b, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ptl_math(nullptr, fn, dA, dB, n, dR);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dR, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (dA) (void)hipFree(dA);
+    if (dR) (void)hipFree(dR);
+    if (dB) (void)hipFree(dB);
+    if (e != hipSuccess) { pt_set_error("pt_math_eval: %s", hipGetErrorString(e)); return PT_EHIP; }
     return PT_OK;
 }
 

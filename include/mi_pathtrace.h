@@ -221,9 +221,14 @@ enum PtOption {
                                     while on, a launch group stays on one stream    */
     PT_OPT_COUNTERS = 4,         /* count nodes/triangles in traversal (default 0)  */
     PT_OPT_USE_GRAPH = 5,        /* hipGraph replay of an iteration: not supported, a non-zero value returns PT_EINVAL */
-    PT_OPT_BATCH = 6             /* iterations that share one launch group in
+    PT_OPT_BATCH = 6,            /* iterations that share one launch group in
                                     pt_trace_range (default 16, at most 512); results
                                     do not depend on it                              */
+    PT_OPT_LAUNCH_STREAMS = 7    /* streams a launch group is spread over: 1..8 fixes the
+                                    count, and pt_trace_range then never waits on the host;
+                                    0 (default) lets the first five groups of a size try
+                                    the shapes, each of those five calls ending with a host
+                                    wait.  Results do not depend on it                  */
 };
 
 /* pathtraceInit (src/pathtrace.cu:428-576): uploads the scene, builds lights,
@@ -252,8 +257,10 @@ int pt_trace(PtContext* ctx, int iter);
  * internally and is joined on the context's stream: the first five groups of a size
  * (12 iterations or more) try the shapes (one, two, three streams, and one stream with
  * the shadow traversal in line instead of beside the next bounce), each of those calls
- * ends with a wait, and the fewest streams within 3 % of the fastest shape are kept
- * (environment PT_STREAMS, 1..8, fixes the count instead). */
+ * ends with a HOST wait, and the fewest streams within 3 % of the fastest shape are kept.
+ * A caller that needs every call to return without waiting fixes the count beforehand:
+ * pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, n) with n in 1..8, or PT_STREAMS=n in the
+ * environment when the context is created; no trial runs then, and no waits. */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE
@@ -306,6 +313,11 @@ int pt_camera_rays(PtContext* ctx, int iter, float* origins, float* directions);
  * the library's sin/cos/acos/atan2/exp/log): evaluates fn on n host inputs
  * (b may be NULL for unary functions) and returns the raw float results. */
 int pt_math_eval(int device, int fn, const float* a, const float* b, int n, float* out);
+
+/* Number of calls the library has made, in this process, that create or release a device-side resource (hipMalloc,
+ * hipFree, pinned host memory, events, streams).  No counterpart in the reference; it lets a caller that may not
+ * allocate — and the test of pt_intersect_rays_noalloc — see that a call made none. */
+unsigned long long pt_resource_calls(void);
 
 const char* pt_last_error(void);
 const char* pt_version(void);

@@ -45,6 +45,7 @@ void pathtraceInit(Scene* scene)
     hst_scene = scene;
     std::vector<PtGeom> geoms;
     std::vector<PtMesh> meshes;
+    size_t loadedModels = 0;            /* models the loader pushed onto scene->meshes so far, empty ones included */
     for (const Geom& g : scene->geoms) {
         PtGeom o;
         memset(&o, 0, sizeof(o));
@@ -59,10 +60,17 @@ void pathtraceInit(Scene* scene)
         o.meshIndex = -1;
         o.triangleStart = -1;
         o.bvhIndex = -1;
-        if (g.type == GLTF_MESH && g.triangleCount > 0) {
-            /* Geom::meshData points at scene->meshes.back() of the moment it was loaded and dangles once a second
-             * model is pushed (src/scene.cpp:535-537): take the mesh by position instead, one per loaded model */
-            const MeshData& md = scene->meshes[meshes.size()];
+        /* Geom::meshData points at scene->meshes.back() of the moment it was loaded and dangles once a second model is
+         * pushed (src/scene.cpp:535-537), so it is only looked at for being set: the loader sets it, and pushes a
+         * MeshData, for every model file it could open — one without triangles included — and leaves it null when the
+         * file would not load.  The mesh itself is taken by position, the n-th loaded model being scene->meshes[n]. */
+        const bool loaded = g.type == GLTF_MESH && g.meshData != nullptr;
+        const size_t modelIndex = loadedModels;
+        if (loaded) ++loadedModels;
+        if (loaded && modelIndex >= scene->meshes.size()) { fprintf(stderr, "pathtraceInit: scene holds %zu models, geom wants model %zu\n", scene->meshes.size(), modelIndex); exit(EXIT_FAILURE); }
+        if (loaded && g.triangleCount > 0) {
+            const MeshData& md = scene->meshes[modelIndex];
+            if ((int)md.triangles.size() != g.triangleCount) { fprintf(stderr, "pathtraceInit: model %zu has %zu triangles, its geom says %d\n", modelIndex, md.triangles.size(), g.triangleCount); exit(EXIT_FAILURE); }
             PtMesh m;
             memset(&m, 0, sizeof(m));
             m.triangles = reinterpret_cast<const PtTriangle*>(md.triangles.data());

@@ -7,13 +7,23 @@
  * (external/include/glm/detail/func_geometric.inl, type_mat4x4.inl:592-628,
  * func_common.inl:409-472) because results are compared bit for bit.
  *
- * PARITY PINS: the reference ships no tests or golden vectors for this path
- * and cannot be built in this image (it needs the CUDA toolkit headers), so
- * the oracle is pinned by the known-answer values that were recorded from a
- * host run of the reference's own kernels (tests/golden/reference_kats.json):
- * RNG stream, hemisphere sample, unit-sphere hit, camera ray, the live-path
- * curve / path-bounce total / mean radiance of cornell.json at 800x800.
- * Anything those values do not exercise is "parity unpinned".
+ * PARITY PINS.  The reference ships no tests or golden vectors for this path.
+ * Where its own sources compile on a host compiler they pin this file
+ * directly: oracle/Makefile builds src/intersections.cu, src/bvh.cpp,
+ * src/scene.cpp, src/utilities.cpp, src/stb.cpp and src/image.cpp unmodified
+ * into oracle/_ref/, and tests/test_reference_build.py holds the closest-hit
+ * half of this file (box, sphere, triangle, AABB, BVH traversal, hit epilogue),
+ * the BVH builder and the loader to them bit for bit.  src/pathtrace.cu and
+ * src/interactions.cu (kernel-launch syntax, thrust device algorithms and
+ * random engines) do not compile on a host compiler without stand-ins, so the
+ * shading half is pinned by the known answers recorded from a host run of the
+ * reference's kernels (tests/golden/reference_kats.json: RNG stream,
+ * hemisphere sample, unit-sphere hit, camera ray, the live-path curve /
+ * path-bounce total / mean radiance of cornell.json at 800x800, the
+ * path-bounce totals of sss.json) and, statistically, by the reference's own
+ * finished renders (tests/test_reference_renders.py).  Texture filtering,
+ * environment-map lookup / importance sampling and GGX against an environment
+ * have no reference-derived value: "parity unpinned".
  *
  * Build with -ffp-contract=off (no FMA contraction).
  */

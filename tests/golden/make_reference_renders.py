@@ -14,7 +14,9 @@ also ships, and three of those scenes need no asset that is missing from its tre
 Each is a 1200 x 1200 8-bit PNG as Image::savePNG wrote it (src/image.cpp:23-37): the outputs of the whole loop —
 camera rays, intersection, the diffuse / specular / PBR / subsurface shaders with their light sampling, gather — after
 hundreds to thousands of iterations.  They are data.  Stored here are the sums of their 8 x 8 pixel blocks per channel
-(uint16, exact), the per-channel means and the SHA-256 of each file, which is all the render tests compare with.
+(uint16, exact), the largest 8-bit value of every block (over its pixels and channels: a block whose maximum is below
+250 holds no pixel the 8-bit conversion clamped), the per-channel means and the SHA-256 of each file, which is all the
+render tests compare with.
 """
 import hashlib
 import os
@@ -46,6 +48,7 @@ def main():
         assert rgba.shape == (1200, 1200, 4) and (rgba[..., 3] == 255).all(), (name, rgba.shape)
         rgb = np.ascontiguousarray(rgba[..., :3])
         out[key + "_sum8"] = block_sums(rgb)
+        out[key + "_max8"] = rgb.reshape(1200 // BLOCK, BLOCK, 1200 // BLOCK, BLOCK, 3).max((1, 3, 4)).astype(np.uint8)
         out[key + "_mean"] = rgb.reshape(-1, 3).mean(0)
         out[key + "_sha256"] = np.array(hashlib.sha256(data).hexdigest())
         print(name, rgb.shape, out[key + "_mean"])

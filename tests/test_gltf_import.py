@@ -282,6 +282,21 @@ def test_import_matches_float32_restatement(pt, scenes, tmp_path, form):
     assert np.array_equal(tex[0], G.expected_rgba(_rand((8, 8, 3), 256, 3), 2))
 
 
+def test_interleaved_file_is_imported_the_reference_way_and_says_so(pt, scenes, tmp_path):
+    """A buffer view's byteStride is not followed (the reference reads attributes tightly packed, src/scene.cpp:363-420):
+    the import still succeeds, and pt_scene_log names every accessor whose stride was ignored; a packed file leaves no
+    such line."""
+    for inter in (False, True):
+        glb, _doc, _data = _build_test_glb(tmp_path, name="s%d.glb" % inter, interleaved=inter)
+        sc = pt.Scene(scenes.write_scene_json("cornell_orig", str(tmp_path)))
+        sc.import_gltf(glb)
+        notes = [l for l in sc.log.splitlines() if "byteStride" in l]
+        if inter:
+            assert len(notes) >= 3 and any("POSITION" in l for l in notes) and any("TEXCOORD_0" in l for l in notes), sc.log
+        else:
+            assert not notes, notes
+
+
 def test_import_errors(pt, scenes, tmp_path):
     sc = _base_scene(pt, scenes, tmp_path)
     with pytest.raises(pt.PtError, match="cannot open"):

@@ -56,24 +56,43 @@ def _bounce3_rays(tr, n, seed):
     return o, d
 
 
-def _ref_check(sc, ro, rd, gpu_hits):
-    """the GPU against the reference's own boxIntersectionTest / sphereIntersectionTest / meshIntersectionTestBVH"""
+def _ref_check(what, sc, ro, rd, gpu_hits):
+    """The GPU against the reference's own boxIntersectionTest / sphereIntersectionTest / meshIntersectionTestBVH
+    (oracle/_ref/ref_tool, a separate process).  Returns the number of rays that were compared and says so on stdout
+    and in gpurun_out/reference_checked.log; without the tool the calling test is SKIPPED, never passed, so a test
+    report shows whether the reference's code was in the loop."""
     if not ref.available():
-        return False
+        pytest.skip("oracle/_ref/ref_tool is absent: %s was not compared with the reference's own intersection code" % what)
     r = ref.intersect(sc, ro, rd)
+    assert len(r) == len(ro) == len(gpu_hits)
     assert np.array_equal(gpu_hits["geom"], r["geom"]) and gpu_hits["t"].tobytes() == r["t"].tobytes()
     hit = r["t"] > 0
     assert np.array_equal(gpu_hits["materialId"][hit], r["materialId"][hit])
     assert gpu_hits["normal"][hit].tobytes() == r["normal"][hit].tobytes() and gpu_hits["uv"][hit].tobytes() == r["uv"][hit].tobytes()
-    return True
+    line = "reference-checked %d rays (%d hits) on %s: GPU == the reference's own intersection code, bit for bit" % (len(ro), int(hit.sum()), what)
+    print(line)
+    try:
+        os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "reference_checked.log"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return len(ro)
 
 
 @pytest.mark.parametrize("name,res,depth,nrays", [("dragon", (128, 128), 8, 100000), ("chess", (128, 72), 10, 100000),
-                                                  ("halo", (96, 96), 8, 100000)])
+                                                  ("halo", (96, 96), 8, 100000), ("p911", (96, 96), 8, 100000)])
 def test_full_size_mesh_bit_exact(pt, scenes, orc, gpu_ok, name, res, depth, nrays):
+    """p911 is the set-up of scenes/911.json:33-46 (one light of emittance 1, environment intensity 3, 16 textured
+    materials on the mesh), halo that of scenes/halo.json (two lights, 13 materials)."""
     sc = scenes.make_scene(name, res=res, depth=depth, tex_size=64, env_size=(256, 128))
     ntri = int(sc.desc.contents.meshes[0].triangleCount)
-    assert ntri == {"dragon": 135200, "chess": 1499912, "halo": 3001250}[name]
+    assert ntri == {"dragon": 135200, "chess": 1499912, "halo": 3001250, "p911": 3001250}[name]
+    if name == "p911":
+        mats = sc.materials()
+        assert len([m for m in mats if m.baseColorTextureIdx >= 0]) == 16 and len(sc.textures()) == 32
+        lights = [m for m in mats if m.emittance > 0]
+        assert len(lights) == 1 and lights[0].emittance == 1.0 and scenes._ASSET_CLASS["p911"]["env_intensity"] == 3.0
     tr = pt.Tracer(sc)
     o = orc.Oracle(pt, sc, orc.MATH_DET)
     ro, rd = _ray_set(31, nrays, center=(0.0, 5.0, 0.0), radius=14.0)
@@ -90,8 +109,6 @@ def test_full_size_mesh_bit_exact(pt, scenes, orc, gpu_ok, name, res, depth, nra
     print("%s: %d triangles, deepest stack %d entries (%d in LDS), %.1f boxes / %.1f triangles per ray" % (
         name, ntri, st.maxStackDepth, st.ldsStackEntries, st.boxesTested / len(ro), st.trisTested / len(ro)))
     assert st.maxStackDepth > st.ldsStackEntries, "no ray reached the spill part of the traversal stack"
-    if name == "dragon":
-        assert _ref_check(sc, ro[:40000], rd[:40000], g[:40000]) or not ref.available()
     # one whole iteration (closest-hit and shadow traversals, sort, shading, compaction) on the full-size tree
     _assert_full_parity(pt, orc, sc, [1])
 
@@ -121,7 +138,6 @@ def test_reference_duck_asset_bit_exact(pt, scenes, orc, gpu_ok, tmp_path):
     g = tr.intersect(ro, rd)
     _hits_equal(g, o.intersect(ro, rd))
     assert (g["triangle"] >= 0).sum() > 3000
-    _ref_check(sc, ro, rd, g)
     _assert_full_parity(pt, orc, sc, [1, 2, 3])
 
 
@@ -173,7 +189,7 @@ def _ulp_shift(a, rng, k=3):
     return out
 
 
-def test_near_coincident_surfaces_bit_exact(pt, scenes, orc, gpu_ok):
+def _near_coincident_case(pt, scenes, orc, full=True):
     """Two copies of a mesh a few ulps apart inside ONE BVH (near-equal distances in different leaves), the same as
     separate geoms, and cubes that share a face plane with each other and with a flat blob face: the reference prunes
     a leaf by its box's entry distance and keeps the first-visited triangle among exact ties; a traversal that
@@ -200,7 +216,6 @@ def test_near_coincident_surfaces_bit_exact(pt, scenes, orc, gpu_ok):
                                 scenes.cube_mesh(((1.0, 7.5, 0.0), (0.0, 0.0, 0.0), (2.0, 1.0, 2.0)), m1),      # overlapping, coplanar faces
                                 scenes.cube_mesh(((0.0, 8.5, 0.0), (0.0, 0.0, 0.0), (2.0, 1.0, 2.0)), m1)]))    # stacked: shared face plane
     tr = pt.Tracer(sc)
-    o = orc.Oracle(pt, sc, orc.MATH_DET)
     ro, rd = _ray_set(41, 120000, center=(0.0, 5.0, 0.0), radius=9.0)
     # axis-parallel rays along the shared planes' normals and grazing along them
     xs = np.linspace(-1.4, 2.4, 60, dtype=np.float32)
@@ -211,6 +226,9 @@ def test_near_coincident_surfaces_bit_exact(pt, scenes, orc, gpu_ok):
     side_d = np.tile(np.array([[1, 0, 0]], np.float32), (gx.size, 1))
     ro, rd = np.concatenate([ro, down_o, side_o]), np.concatenate([rd, down_d, side_d])
     g = tr.intersect(ro, rd)
+    if not full:
+        return sc, ro, rd, g
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
     ob = o.intersect(ro, rd)
     _hits_equal(g, ob)
     mesh_hits = g[g["triangle"] >= 0]
@@ -218,8 +236,130 @@ def test_near_coincident_surfaces_bit_exact(pt, scenes, orc, gpu_ok):
     # both copies of the doubled mesh win somewhere: the near-ties are real
     first = mesh_hits[mesh_hits["geom"] == min(mesh_hits["geom"])]
     assert 0 < (first["materialId"] == m0).sum() < len(first)
-    _ref_check(sc, ro, rd, g)
     _assert_full_parity(pt, orc, sc, [1, 2])
+    return sc, ro, rd, g
+
+
+def test_near_coincident_surfaces_bit_exact(pt, scenes, orc, gpu_ok):
+    _near_coincident_case(pt, scenes, orc)
+
+
+def _big_quads(pt, rng, count, size, material_ids):
+    """`count` quads of two triangles each, `size` scene units across, stacked a few 1e-6 apart and tilted by a few
+    1e-7 against each other: triangle edges are as long as the mesh, and from a starting point a millimetre in front of
+    the stack the distances to neighbouring quads differ in the last digits."""
+    tris = np.zeros(2 * count, dtype=pt.TRI_DTYPE)
+    for q in range(count):
+        z = -1.0 + q * 3e-6
+        c = np.array([[-size / 2, 5 - size / 2, z], [size / 2, 5 - size / 2, z], [size / 2, 5 + size / 2, z], [-size / 2, 5 + size / 2, z]], np.float64)
+        c[:, 2] += rng.uniform(-4e-7, 4e-7, 4)
+        c = c.astype(np.float32)
+        for k, tri in enumerate(((0, 1, 2), (0, 2, 3))):
+            t = tris[2 * q + k]
+            t["v0"], t["v1"], t["v2"] = c[list(tri)]
+            t["n0"] = t["n1"] = t["n2"] = (0.0, 0.0, 1.0)
+            t["uv0"], t["uv1"], t["uv2"] = (0, 0), (1, 0), (1, 1)
+            t["materialId"] = material_ids[q % len(material_ids)]
+    return tris
+
+
+def _short_range_rays(rng, n):
+    # starting points 1e-4 .. 1e-2 in front of the stack: along the shared diagonal, along the rim, anywhere
+    u = rng.uniform(-3.999, 3.999, n)
+    on_diag = np.stack([u, 5 + u + rng.uniform(-2e-4, 2e-4, n)], 1)
+    on_rim = np.stack([np.where(rng.rand(n) < 0.5, -4.0, 4.0) + rng.uniform(-2e-4, 2e-4, n), 5 + u], 1)
+    anywhere = np.stack([rng.uniform(-4, 4, n), 5 + rng.uniform(-4, 4, n)], 1)
+    pick = rng.randint(0, 3, n)[:, None]
+    xy = np.where(pick == 0, on_diag, np.where(pick == 1, on_rim, anywhere))
+    z = -1.0 + 10.0 ** rng.uniform(-4, -2, n)
+    inside = rng.rand(n) < 0.3                                         # a third start between the quads: hits a few 1e-6 away
+    z[inside] = -1.0 + rng.uniform(0.0, 2.7e-5, inside.sum())
+    ro = np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+    rd = np.concatenate([rng.normal(0, 0.3, (n, 2)), -np.ones((n, 1))], 1)
+    rd[inside & (rng.rand(n) < 0.5), 2] = 1.0                          # and half of those look the other way
+    graze = rng.rand(n) < 0.25
+    rd[graze, 2] = np.sign(rd[graze, 2]) * 10.0 ** rng.uniform(-4, -1, graze.sum())      # nearly parallel to the stack
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    return ro, rd
+
+
+def test_large_triangles_hit_at_short_range_bit_exact(pt, scenes, orc, gpu_ok):
+    """The regime in which a triangle's distance is least exact relative to itself: triangles as large as the mesh, hit
+    from a millimetre away, near the edge two triangles share and near the rim, with neighbours a few 1e-6 behind.  The
+    error of the triangle test scales with the triangle, not with the distance, so the relative slack of the walked
+    boxes (2^-15 of the distance) does not cover it; the absolute pad of the walked boxes (2^-20 of the mesh extent)
+    has to.  GPU == oracle == the reference's own code on every ray."""
+    sc = scenes.make_scene("cornell_orig", res=(48, 48), depth=8)
+    m = [sc.add_material(type=pt.PT_PBR, color=[0.2 + 0.1 * k, 0.5, 0.9 - 0.1 * k], roughness=0.4, metallic=0.0, indexOfRefraction=1.5) for k in range(4)]
+    rng = np.random.RandomState(29)
+    sc.add_mesh(_big_quads(pt, rng, 9, 8.0, m))
+    n = 60000
+    ro, rd = _short_range_rays(rng, n)
+    tr = pt.Tracer(sc)
+    o = orc.Oracle(pt, sc, orc.MATH_DET)
+    g = tr.intersect(ro, rd)
+    _hits_equal(g, o.intersect(ro, rd))
+    on_mesh = g[g["triangle"] >= 0]
+    assert len(on_mesh) > n // 2 and len(set(on_mesh["triangle"].tolist())) >= 6
+    if ref.available():
+        _ref_check("large triangles at short range", sc, ro, rd, g)
+    _assert_full_parity(pt, orc, sc, [1, 2])
+
+
+@pytest.mark.parametrize("case", ["dragon_full_size", "p911_full_size", "duck_glb", "near_coincident", "cornell_primitives"])
+def test_gpu_equals_reference_own_intersection_code(pt, scenes, orc, gpu_ok, tmp_path, case):
+    """The GPU's closest hits against the reference's OWN code — src/intersections.cu, src/bvh.cpp compiled unmodified as
+    oracle/_ref/ref_tool — with no restatement in between: distance, geom, material, normal and uv bit for bit.  Skipped
+    (visibly) when the tool did not travel; every comparison that ran leaves a 'reference-checked N rays' line."""
+    if case == "dragon_full_size":
+        sc = scenes.make_scene("dragon", res=(64, 64), depth=8, tex_size=16, env_size=(64, 32))
+        tr = pt.Tracer(sc)
+        ro, rd = _ray_set(31, 30000, center=(0.0, 5.0, 0.0), radius=14.0)
+        bo, bd = _bounce3_rays(tr, 30000, 7)
+        ro, rd = np.concatenate([ro, bo]), np.concatenate([rd, bd])
+        g = tr.intersect(ro, rd)
+    elif case == "p911_full_size":
+        sc = scenes.make_scene("p911", res=(64, 64), depth=8, tex_size=16, env_size=(64, 32))
+        tr = pt.Tracer(sc)
+        ro, rd = _ray_set(33, 20000, center=(0.0, 5.0, 0.0), radius=14.0)
+        bo, bd = _bounce3_rays(tr, 20000, 9)
+        ro, rd = np.concatenate([ro, bo]), np.concatenate([rd, bd])
+        g = tr.intersect(ro, rd)
+    elif case == "duck_glb":
+        sc = _duck_scene(pt, scenes, tmp_path, (96, 96))
+        tr = pt.Tracer(sc)
+        ro, rd = _ray_set(5, 60000, center=(0.0, 2.0, 0.0), radius=10.0)
+        g = tr.intersect(ro, rd)
+    elif case == "near_coincident":
+        sc, ro, rd, g = _near_coincident_case(pt, scenes, orc, full=False)
+    else:
+        sc = scenes.make_scene("cornell", res=(64, 64))
+        tr = pt.Tracer(sc)
+        ro, rd = _ray_set(11, 40000)
+        g = tr.intersect(ro, rd)
+    assert (g["t"] > 0).sum() > len(ro) // 10
+    assert _ref_check(case, sc, ro, rd, g) == len(ro)
+
+
+def test_4k_resolution_batched_equals_single(pt, scenes, gpu_ok):
+    """3840 x 2160 (the resolution of the 911 / halo configuration) on the 3-million-triangle model: two iterations in
+    one launch group equal two one-iteration calls bit for bit, every pixel sum is finite and non-negative, the
+    path-bounce totals agree and every pixel entered bounce 0."""
+    sc = scenes.make_scene("halo", res=(3840, 2160), depth=8, tex_size=64, env_size=(256, 128))
+    tr = pt.Tracer(sc)
+    tr.set_option(pt.PT_OPT_BATCH, 2)
+    tr.trace_range(1, 3)
+    a = tr.image().copy()
+    pb = tr.stats().pathBounces
+    assert tr.stats().lastLive[0] == 3840 * 2160
+    tr.clear()
+    tr.reset_stats()
+    tr.trace(1)
+    tr.trace(2)
+    b = tr.image()
+    assert tr.stats().pathBounces == pb and pb > 2 * 3840 * 2160
+    assert np.isfinite(a).all() and (a >= 0).all() and float(a.sum()) > 0
+    assert _same_bits(a, b)
 
 
 @pytest.mark.parametrize("name,kw", [("sss", dict(res=(96, 96), depth=8)), ("pbr", dict(res=(96, 96), depth=8, env=True, env_size=(256, 128))),

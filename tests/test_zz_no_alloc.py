@@ -26,8 +26,19 @@ def test_no_alloc_entry_point_matches_allocating_one(pt, scenes, gpu_ok):
     sc = scenes.make_scene("dragon", res=(96, 96), grid=(64, 65), env_size=(64, 32), tex_size=16)
     tr = pt.Tracer(sc)
     ro, rd = _rays(21, 60000)
+    import torch
+    calls0 = pt.lib.pt_resource_calls()
     want = tr.intersect(ro, rd)
+    calls1 = pt.lib.pt_resource_calls()
+    assert calls1 > calls0, "the allocating entry point is expected to allocate its staging buffers"
+    tr.intersect_noalloc(ro, rd)                     # first use: nothing may be left to set up lazily either
+    free0 = torch.cuda.mem_get_info()[0]
+    calls1 = pt.lib.pt_resource_calls()
     got = tr.intersect_noalloc(ro, rd)
+    # the property the entry point exists for: no device memory, pinned memory, event or stream was created or
+    # released by the call (the library counts every such call it makes), and the device's free memory did not move
+    assert pt.lib.pt_resource_calls() == calls1
+    assert torch.cuda.mem_get_info()[0] == free0
     assert (want["triangle"] >= 0).sum() > 5000 and (want["t"] < 0).sum() > 100
     assert _identical(got, want)
     # second call, smaller input: entries beyond it must stay untouched, the first ones must be this call's
@@ -49,6 +60,11 @@ def test_no_alloc_entry_point_matches_allocating_one(pt, scenes, gpu_ok):
     rb, db = _rays(24, n + 1)
     full = tr.intersect_noalloc(rb[:n], db[:n])
     assert _identical(full, tr.intersect(rb[:n], db[:n]))
+    calls2 = pt.lib.pt_resource_calls()
     with pytest.raises(pt.PtError, match="exceed"):
         tr.intersect_noalloc(rb, db)
     assert len(tr.intersect_noalloc(rb[:0], db[:0])) == 0
+    tr.set_option(pt.PT_OPT_COUNTERS, 1)            # the counted kernels and stage timing do not make it allocate either
+    tr.set_option(pt.PT_OPT_STAGE_TIMING, 1)
+    assert _identical(tr.intersect_noalloc(ro2, rd2), out[:7001])
+    assert pt.lib.pt_resource_calls() == calls2
