@@ -49,6 +49,7 @@ CLOCK_GHZ = 2.4
 # for packed / dual-issue forms = the 157.3 TFLOP/s headline figure)
 VALU_LANE_PEAK_GINST = 256 * 4 * 16 * CLOCK_GHZ
 VALU_PEAK_TFLOPS = 157.3
+L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth of the eight XCDs
 TUNE_GROUPS = 5      # launch groups the library uses to pick its launch shape (one unmeasured, then 1 / 2 / 3 streams and one stream alone)
 
 
@@ -230,7 +231,7 @@ def main():
     cs = tr.stats()
     counted = dict(pb=cs.pathBounces, rays=cs.tracedRays, shadow_rays=cs.shadowRays,
                    boxes=cs.boxesTested - cs.shadeBoxesTested, tris=cs.trisTested - cs.shadeTrisTested, hits=cs.meshHits - cs.shadeMeshHits,
-                   s_boxes=cs.shadeBoxesTested, s_tris=cs.shadeTrisTested, max_stack=cs.maxStackDepth)
+                   s_boxes=cs.shadeBoxesTested, s_tris=cs.shadeTrisTested, max_stack=cs.maxStackDepth, ref_walks=cs.referenceOrderWalks)
     tr.set_option(pt.PT_OPT_COUNTERS, 0)
     tr.reset_stats()
     tr.clear()
@@ -308,25 +309,32 @@ def main():
             traffic_per_ray = k.get("hbm_bytes_per_ray")
             achieved = (lane_inst_per_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if (lane_inst_per_ray and avg_ms > 0) else None
             traffic = round(traffic_per_ray * rays_per_launch) if traffic_per_ray else None
-            roofline = {"bound": "valu_issue", "kernel": "k_trace<closest>",
-                        "achieved": round(achieved, 1) if achieved else None, "peak": round(VALU_LANE_PEAK_GINST, 1),
-                        "unit": "G fp32-lane instructions/s",
-                        "frac": round(achieved / VALU_LANE_PEAK_GINST, 4) if achieved else None,
+            util = round(achieved / VALU_LANE_PEAK_GINST, 4) if achieved else None
+            roofline = {"bound": "valu", "kernel": "k_trace<closest>",
+                        "achieved": round(valu_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
+                        "utilisation": util,
+                        "utilisation_detail": {"lane_instructions_G_per_s": round(achieved, 1) if achieved else None,
+                                               "peak_G_per_s": round(VALU_LANE_PEAK_GINST, 1),
+                                               "issue_utilisation": k.get("valu_issue_utilisation"),
+                                               "lane_utilisation": k.get("valu_lane_utilisation")},
+                        "l2_view": {"achieved": round(alg_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / L2_PEAK_GBS, 4)},
                         "traffic": traffic,
                         "traffic_gbs": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None),
                         "hbm_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None),
-                        "issue_utilisation": k.get("valu_issue_utilisation"), "lane_utilisation": k.get("valu_lane_utilisation"),
                         "l2_hit_rate": k.get("l2_hit_rate"),
                         "counters_from": ("profiles/pmc_%s.json (rocprofv3 --pmc passes of this workload)" % args.workload) if k else None,
-                        "note": "the BVH is served by L2 / Infinity Cache: the kernel is bound by vector instruction issue under lane divergence "
-                                "(frac = issue utilisation x lane utilisation), not by HBM (hbm_frac = measured HBM traffic / 8 TB/s); "
-                                "alg_gbs is the algorithmic-byte rate (32 B per child box tested, 36 B per triangle, 64 B per mesh hit, 80 B of "
-                                "path state and hit record per ray), which the caches serve and which therefore is no fraction of HBM bandwidth",
-                        "alg_bytes_per_ray": round(b_ray, 1), "alg_gbs": round(alg_gbs, 1), "rays_per_launch": round(rays_per_launch, 1),
+                        "note": "frac = algorithmic flops (30 per child box slab-tested, 53 per triangle tested, 36 per ray-to-object-space transform, "
+                                "120 per hit epilogue) / launch duration / the 157.3 TFLOP/s fp32 vector peak; utilisation = share of the machine's "
+                                "fp32 lane-instruction slots the kernel fills (issue utilisation x lane utilisation, from the counters: it counts every "
+                                "vector instruction, addressing and stack traffic included); l2_view = algorithmic bytes (32 per child box, 36 per "
+                                "triangle, 64 per mesh hit, 80 of path state and hit record per ray) / launch duration / the 34.5 TB/s aggregate L2 "
+                                "bandwidth - the BVH is served by L1 / L2 / Infinity Cache, so HBM is not the ceiling (hbm_frac = counter-measured HBM "
+                                "traffic / 8 TB/s)",
+                        "alg_bytes_per_ray": round(b_ray, 1), "alg_flops_per_ray": round(flops_ray, 1), "rays_per_launch": round(rays_per_launch, 1),
                         "avg_launch_ms": round(avg_ms, 5), "launches": st.launchesTrace,
                         "boxes_per_ray": round(boxes, 2), "tris_per_ray": round(tris, 2), "mesh_hit_rate": round(hits, 3),
-                        "deepest_stack": counted["max_stack"],
-                        "valu_fp32_tflops": round(valu_tflops, 2), "valu_fp32_peak_tflops": VALU_PEAK_TFLOPS,
+                        "deepest_stack": counted["max_stack"], "reference_order_walks_per_million_rays": round(1e6 * counted["ref_walks"] / max(counted["rays"] + counted["shadow_rays"], 1), 2),
                         "stage_ms_per_spp": {k2: round(v / max(spp_rank, 1), 4) for k2, v in stages.items()},
                         "measured_in": measured_in}
         else:
@@ -387,6 +395,43 @@ def main():
                                           "how": "pt_trace(iteration) once per sample per pixel, no host copy, one wait at the end: up to calls_in_flight calls "
                                                  "overlap on the device (a row of the path state and a stream each, accumulation in call order); "
                                                  "the second figure has a host wait after every call, nothing overlaps"}
+            # ---- the same loop at the rate of launch groups: pt_trace_lookahead renders the iterations behind the one asked for in the
+            # same launch group and hands them out one per call; the running sum is copied into a page-locked host image after
+            # every call, as the reference's pathtrace() does (src/pathtrace.cu:2913-2917).  This is the call sequence of
+            # integration/pathtrace_mi355x.cpp (the file a maintainer of the reference adds), made through the C ABI.
+            import numpy as np
+            ahead = int(os.environ.get("PT_LOOKAHEAD", "64") or 64)
+            ahead = max(2, min(ahead, B // 2))
+            host = np.zeros((res[1], res[0], 3), np.float32)
+            tr.set_option(pt.PT_OPT_LAUNCH_STREAMS, 1)
+            tr.clear()
+            tr.bind_host_image(host)
+            n_calls = 4 * ahead
+            f0 = time.perf_counter()
+            tr.trace_lookahead(1, ahead)
+            tr.host_image_wait()
+            f1 = time.perf_counter()
+            for it in range(2, 2 + n_calls):
+                tr.trace_lookahead(it, ahead)
+                tr.host_image_wait()                    # the host image is read after every call
+            f2 = time.perf_counter()
+            for it in range(2 + n_calls, 2 + 2 * n_calls):
+                tr.trace_lookahead(it, ahead)           # the host copy is queued behind every call, waited for once
+            tr.host_image_wait()
+            f3 = time.perf_counter()
+            check = tr.image()
+            ok = bool((host.view(np.uint32) == check.view(np.uint32)).all())
+            tr.sync()
+            tr.bind_host_image(None)
+            tr.set_option(pt.PT_OPT_LAUNCH_STREAMS, 0)
+            extras["pathtrace_call"] = {"ms_per_call_host_image_current_after_every_call": round((f2 - f1) / n_calls * 1e3, 4),
+                                        "ms_per_call_host_copy_queued": round((f3 - f2) / n_calls * 1e3, 4),
+                                        "first_call_ms": round((f1 - f0) * 1e3, 2), "calls": n_calls, "iterations_rendered_ahead": ahead,
+                                        "host_copy_bytes_per_call": int(npix * 12), "host_image_equals_device_sum": ok,
+                                        "path_state_bytes": int(195 * npix) * 2 * ahead,
+                                        "how": "pt_trace_lookahead(iteration, ahead) + pt_host_image_wait once per sample per pixel: the call sequence of "
+                                               "pathtrace(pbo = NULL, frame, iteration) in integration/pathtrace_mi355x.cpp, device-to-host copy of the running "
+                                               "sum (W*H*12 bytes) included; the first call renders a whole group before it returns"}
             extras["path_state_bytes_in_flight"] = int(192 * npix) * B
             if st.launchesTrace > 0:
                 extras["ray_sets"] = _ray_sets(pt, tr, npix)

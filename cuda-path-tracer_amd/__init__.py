@@ -100,7 +100,7 @@ class PtStats(C.Structure):
                 ("launchesTrace", C.c_uint32), ("launchesShadowTrace", C.c_uint32),
                 ("tracedRays", C.c_uint64), ("shadowRays", C.c_uint64),
                 ("boxesTested", C.c_uint64), ("shadeBoxesTested", C.c_uint64),
-                ("maxStackDepth", C.c_uint32), ("ldsStackEntries", C.c_uint32)]
+                ("maxStackDepth", C.c_uint32), ("ldsStackEntries", C.c_uint32), ("referenceOrderWalks", C.c_uint64)]
 
 
 class PtError(RuntimeError):
@@ -119,6 +119,9 @@ def _load():
         "pt_destroy": (ip, [vp]),
         "pt_trace": (ip, [vp, ip]),
         "pt_trace_range": (ip, [vp, ip, ip, ip]),
+        "pt_trace_lookahead": (ip, [vp, ip, ip, ip]),
+        "pt_bind_host_image": (ip, [vp, vp]),
+        "pt_host_image_wait": (ip, [vp]),
         "pt_display": (ip, [vp, ip, vp]),
         "pt_download": (ip, [vp, vp]),
         "pt_bind_image": (ip, [vp, vp]),
@@ -402,6 +405,24 @@ class Tracer:
 
     def trace_range(self, begin, end, stride=1):
         _check(lib.pt_trace_range(self._h, int(begin), int(end), int(stride)), "pt_trace_range")
+
+    def trace_lookahead(self, it, ahead, last=0):
+        """pathtrace() once per frame at the rate of launch groups: see pt_trace_lookahead."""
+        _check(lib.pt_trace_lookahead(self._h, int(it), int(ahead), int(last)), "pt_trace_lookahead")
+
+    def bind_host_image(self, array):
+        """array: C-contiguous float32 of W*H*3 elements that receives the running sum after every trace_lookahead call
+        (None unbinds); host_image_wait() blocks until the latest copy has landed."""
+        if array is None:
+            self._host_image = None
+            _check(lib.pt_bind_host_image(self._h, None), "pt_bind_host_image")
+            return
+        assert array.dtype == np.float32 and array.flags["C_CONTIGUOUS"] and array.size == self.width * self.height * 3
+        self._host_image = array            # kept alive while bound
+        _check(lib.pt_bind_host_image(self._h, array.ctypes.data), "pt_bind_host_image")
+
+    def host_image_wait(self):
+        _check(lib.pt_host_image_wait(self._h), "pt_host_image_wait")
 
     def sync(self):
         _check(lib.pt_sync(self._h), "pt_sync")

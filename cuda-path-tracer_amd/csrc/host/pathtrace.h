@@ -30,13 +30,23 @@ void InitDataContainer(GuiDataContainer* guiData);
 void pathtraceInit(Scene* scene);
 void pathtraceFree();
 /* pbo: DEVICE pointer to W*H uchar4 or nullptr (headless); frame is unused as in the reference
- * (src/main.cpp:825-826).  After the call the scene's host image holds the running sum. */
+ * (src/main.cpp:825-826).  After the call the scene's host image holds the running sum.
+ * The reference's loop calls this once per frame with iteration = 1, 2, 3, ...: the iterations behind the one asked
+ * for are rendered ahead in the same launch group (pathtraceSetLookahead) and every later call only adds its own, so
+ * the image after call k is bit for bit the sum of iterations 1..k while the device works at the rate of launch groups. */
 void pathtrace(uchar4* pbo, int frame, int iteration);
 
 /* additions for headless use */
 void pathtraceInitDesc(const PtSceneDesc* desc, float* hostImage);     /* any scene source; hostImage may be null */
 void pathtraceSetMaterialSorting(int on);
-void pathtraceSetHostCopy(int on);          /* 0: skip the per-iteration device-to-host copy (default 1, as the reference) */
+/* the per-iteration copy of the running sum into the scene's host image (src/pathtrace.cu:2913-2917):
+ * 1 (default, as the reference) every pathtrace() returns with the host image up to date; 2 the copy is queued behind the
+ * call and pathtraceHostImageWait() waits for the latest one (before saveImage reads the image); 0 no copy */
+void pathtraceSetHostCopy(int mode);
+void pathtraceHostImageWait();
+/* iterations rendered ahead of the calls (default 64, environment PT_LOOKAHEAD; 0 or 1: one iteration per call).  Path
+ * state for twice as many iterations is allocated, about 195 bytes per pixel each. */
+void pathtraceSetLookahead(int iterations);
 void pathtraceRange(int firstIteration, int lastIterationInclusive);    /* batched iterations, then one host copy */
 PtContext* pathtraceContext();
 

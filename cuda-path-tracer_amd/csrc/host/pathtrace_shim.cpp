@@ -13,6 +13,10 @@ GuiDataContainer* g_gui = nullptr;
 float* g_hostImage = nullptr;
 int g_sort = MATERIAL_SORTING;
 int g_hostCopy = 1;
+int g_lookahead = -1;           /* iterations rendered ahead of the calls; -1: PT_LOOKAHEAD or the default */
+int g_ahead = 0;                /* what the context in use was set up for (0: one iteration per call) */
+int g_traceDepth = 0, g_lastIteration = 0;
+constexpr int kDefaultLookahead = 64;
 
 void check(int rc, const char* what)
 {
@@ -25,12 +29,32 @@ void check(int rc, const char* what)
 
 void InitDataContainer(GuiDataContainer* guiData) { g_gui = guiData; }
 
+/* pathtrace() is called once per frame with iteration = 1, 2, 3, ... (src/main.cpp:812-837): the iterations after the one
+ * asked for are rendered in the same launch group, `ahead` at a time, and handed out one per call (pt_trace_lookahead).
+ * Two halves of the path-state rows take turns, so 2 * ahead rows are allocated; when the device cannot hold them the
+ * look-ahead is halved until it can. */
+static void setUpLookahead()
+{
+    int want = g_lookahead;
+    if (want < 0) { const char* e = getenv("PT_LOOKAHEAD"); want = e ? atoi(e) : kDefaultLookahead; }
+    g_ahead = 0;
+    for (int a = want > 256 ? 256 : want; a >= 2; a /= 2)
+        if (pt_set_option(g_ctx, PT_OPT_BATCH, 2 * a) == PT_OK) { g_ahead = a; break; }
+    /* one stream per launch group: the rows ahead are rendered beside the calls that consume them, a host wait
+     * inside a call (the library's trial of launch shapes) would stall the caller */
+    check(pt_set_option(g_ctx, PT_OPT_LAUNCH_STREAMS, 1), "pathtraceInit");
+}
+
 void pathtraceInitDesc(const PtSceneDesc* desc, float* hostImage)
 {
     pathtraceFree();
     check(pt_create(desc, 0, &g_ctx), "pathtraceInit");
     check(pt_set_option(g_ctx, PT_OPT_MATERIAL_SORT, g_sort), "pathtraceInit");
     g_hostImage = hostImage;
+    g_traceDepth = desc->traceDepth;
+    g_lastIteration = desc->iterations;
+    setUpLookahead();
+    if (g_hostImage && g_hostCopy) check(pt_bind_host_image(g_ctx, g_hostImage), "pathtraceInit");
 }
 
 void pathtraceInit(Scene* scene)
@@ -41,34 +65,34 @@ void pathtraceInit(Scene* scene)
 
 void pathtraceFree()
 {
-    if (g_ctx) pt_destroy(g_ctx);
+    if (g_ctx) pt_destroy(g_ctx);           /* unbinds the host image */
     g_ctx = nullptr;
     g_hostImage = nullptr;
-}
-
-static void afterTrace(uchar4* pbo, int iteration)
-{
-    if (pbo) check(pt_display(g_ctx, iteration, reinterpret_cast<uint8_t*>(pbo)), "pathtrace");
-    if (g_gui) {
-        PtStats st;
-        check(pt_stats(g_ctx, &st), "pathtrace");
-        g_gui->TracedDepth = (int)st.lastDepth;                 /* src/pathtrace.cu:2712-2715 */
-    }
-    if (g_hostCopy && g_hostImage) check(pt_download(g_ctx, g_hostImage), "pathtrace");   /* src/pathtrace.cu:2913-2917 */
 }
 
 void pathtrace(uchar4* pbo, int /*frame*/, int iteration)
 {
     if (!g_ctx) { fprintf(stderr, "pathtrace: pathtraceInit has not been called\n"); exit(EXIT_FAILURE); }
-    check(pt_trace(g_ctx, iteration), "pathtrace");
-    afterTrace(pbo, iteration);
+    if (g_gui) g_gui->TracedDepth = g_traceDepth;               /* src/pathtrace.cu:2712-2715 */
+    /* iterations beyond the scene's ITERATIONS are never asked for by the reference's loop (src/main.cpp:831-837): none are rendered ahead */
+    check(pt_trace_lookahead(g_ctx, iteration, g_ahead > 0 ? g_ahead : 1, iteration <= g_lastIteration ? g_lastIteration : 0), "pathtrace");
+    if (pbo) check(pt_display(g_ctx, iteration, reinterpret_cast<uint8_t*>(pbo)), "pathtrace");
+    /* the running sum reaches the host image after every call (src/pathtrace.cu:2913-2917); mode 1 waits for it here, as the
+     * reference's blocking copy does, mode 2 leaves the copy in flight until pathtraceHostImageWait() */
+    if (g_hostCopy == 1 && g_hostImage) check(pt_host_image_wait(g_ctx), "pathtrace");
+}
+
+void pathtraceHostImageWait()
+{
+    if (g_ctx && g_hostImage) check(pt_host_image_wait(g_ctx), "pathtraceHostImageWait");
 }
 
 void pathtraceRange(int first, int lastInclusive)
 {
     if (!g_ctx) { fprintf(stderr, "pathtraceRange: pathtraceInit has not been called\n"); exit(EXIT_FAILURE); }
+    if (g_gui) g_gui->TracedDepth = g_traceDepth;
     check(pt_trace_range(g_ctx, first, lastInclusive + 1, 1), "pathtraceRange");
-    afterTrace(nullptr, lastInclusive);
+    if (g_hostCopy && g_hostImage) check(pt_download(g_ctx, g_hostImage), "pathtraceRange");
 }
 
 void pathtraceSetMaterialSorting(int on)
@@ -76,5 +100,14 @@ void pathtraceSetMaterialSorting(int on)
     g_sort = on ? 1 : 0;
     if (g_ctx) check(pt_set_option(g_ctx, PT_OPT_MATERIAL_SORT, g_sort), "pathtraceSetMaterialSorting");
 }
-void pathtraceSetHostCopy(int on) { g_hostCopy = on ? 1 : 0; }
+void pathtraceSetHostCopy(int mode)
+{
+    g_hostCopy = mode < 0 ? 0 : mode > 2 ? 2 : mode;
+    if (g_ctx) check(pt_bind_host_image(g_ctx, (g_hostCopy && g_hostImage) ? g_hostImage : nullptr), "pathtraceSetHostCopy");
+}
+void pathtraceSetLookahead(int iterations)
+{
+    g_lookahead = iterations;
+    if (g_ctx) setUpLookahead();
+}
 PtContext* pathtraceContext() { return g_ctx; }

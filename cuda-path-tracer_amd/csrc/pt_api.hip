@@ -53,6 +53,7 @@ void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch 
 void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride);
+void ptl_accumulate(hipStream_t s, PathState st, int rows, float* image);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
 void ptl_gbuffer(hipStream_t s, PathState st, const PtMaterial* materials, int n, float* normals, float* albedo);
 void ptl_average(hipStream_t s, const float* sum, float samples, size_t n3, float* out);
@@ -147,6 +148,24 @@ struct PtContext {
     int tuneStage = 0, tuneChoice = 1;  /* for full groups of `batch` iterations; reset when the batch size is set */
     float tuneMs[kMaxStreamGroups + 1] = {};
     hipEvent_t tuneStart = nullptr, tuneEnd = nullptr;
+    /* pt_trace_lookahead: iterations rendered ahead of the calls that ask for them.  `cur` is the launch group whose rows
+     * are being handed out (one per call, in order), `next` the group launched behind it on the other half of the path
+     * state rows, so that the device renders while the caller consumes.  A row's contribution joins the running sum on the
+     * serve stream when its iteration is asked for; the main stream waits for every such addition, so everything
+     * issued on it later (the next group that reuses the rows, pt_sync, pt_download) is ordered behind. */
+    struct AheadGroup { int base = 0, count = 0, rowBase = 0; bool valid = false; hipEvent_t done = nullptr; };
+    AheadGroup aheadCur, aheadNext;
+    int aheadServed = 0;
+    hipStream_t serveStream = nullptr;
+    hipEvent_t servedEvent = nullptr, sumReadyEvent = nullptr;
+    bool sumTouchedOnMain = true;       /* the main stream has written the running sum since the serve stream last waited for it */
+    /* host image (pt_bind_host_image): the caller's W*H*3 floats, page-locked in place when the runtime allows, else
+     * reached through a pinned staging buffer of the library's own */
+    float* hostImage = nullptr;
+    bool hostRegistered = false;
+    float* hostStaging = nullptr;
+    hipEvent_t hostCopyDone = nullptr;
+    bool hostCopyPending = false;
     PtCamera cam{};
     int traceDepth = 8;
     int numPixels = 0;
@@ -772,8 +791,13 @@ int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nn
             UpperTree U;
             float ext = 0.0f;
             for (int k = 0; k < 3; ++k) ext = std::max(ext, nodes[0].bmax[k] - nodes[0].bmin[k]);
-            /* a box of no thickness gets some: the walked boxes only have to contain their triangle */
-            const float pad = ext * (1.0f / 1048576.0f);
+            /* The walked boxes have to contain every point at which the triangle test can report a hit: the test accepts
+             * points a rounding error outside the triangle's rim, and that error is a few units in the last place of the
+             * largest coordinate difference it forms (origin - vertex, an edge), whatever the size of the hit distance.
+             * For origins within a few mesh extents that is a few parts in 10^7 of the extent; the pad is 2^-17 of it
+             * (64 such units).  For origins far outside, the distance itself is as large as those differences and the
+             * relative slack of the box test (kBoxSlack) covers the error.  The pad also gives a flat box some thickness. */
+            const float pad = ext * (1.0f / 131072.0f);
             for (int i = 0; i < nnodes; ++i) {
                 if (!F.seen[i] || nodes[i].leftChild != -1) continue;
                 for (int j = 0; j < nodes[i].triangleCount; ++j) {
@@ -1005,6 +1029,12 @@ int pt_destroy(PtContext* c)
         if (c->shadowStreams[g]) (void)hipStreamSynchronize(c->shadowStreams[g]);
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->serveStream) (void)hipStreamSynchronize(c->serveStream);
+    if (c->hostImage && c->hostRegistered) (void)hipHostUnregister(c->hostImage);
+    if (c->hostStaging) (void)hipHostFree(c->hostStaging);
+    if (c->serveStream) (void)hipStreamDestroy(c->serveStream);
+    for (hipEvent_t e : { c->servedEvent, c->sumReadyEvent, c->hostCopyDone, c->aheadCur.done, c->aheadNext.done })
+        if (e) (void)hipEventDestroy(e);
     resolveSpans(c);
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
     for (void* p : c->allocs) (void)hipFree(p);
@@ -1069,6 +1099,17 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     TRY_HIP(hipEventCreateWithFlags(&c->hintEvent, hipEventDisableTiming));
     TRY_HIP(hipEventCreate(&c->tuneStart));
     TRY_HIP(hipEventCreate(&c->tuneEnd));
+    {
+        /* additions to the running sum and copies to the host run beside the rendering of the rows ahead: highest priority */
+        int lo = 0, hi = 0;
+        TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        TRY_HIP(hipStreamCreateWithPriority(&c->serveStream, hipStreamNonBlocking, hi));
+    }
+    TRY_HIP(hipEventCreateWithFlags(&c->servedEvent, hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&c->sumReadyEvent, hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&c->hostCopyDone, hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&c->aheadCur.done, hipEventDisableTiming));
+    TRY_HIP(hipEventCreateWithFlags(&c->aheadNext.done, hipEventDisableTiming));
     TRY_HIP(hipHostMalloc((void**)&c->liveHintHost, sizeof(uint32_t) * (PT_MAX_DEPTH + 2), hipHostMallocDefault));
     { const char* e = getenv("PT_SPARSE"); if (e) c->sparseMode = atoi(e); }
     for (int g = 0; g < kMaxStreamGroups; ++g) {
@@ -1096,6 +1137,8 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     std::vector<DGeom> geoms(d->geomCount);
     std::vector<float4> allNodes, allHot, allCold, allBox;
     std::vector<int> allLeafOfOrig;
+    std::vector<PtBvhNode> allHostNodes;        /* the host BVHs as built, for travReference */
+    std::vector<int32_t> allHostIndices;
     for (int i = 0; i < d->geomCount; ++i) {
         const PtGeom& g = d->geoms[i];
         DGeom& G = geoms[i];
@@ -1117,6 +1160,12 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
             PtBvhNode root{};
             if (nodes && nn > 0) root = nodes[0];          /* copied: a BVH built here is freed right after flattening */
             rc = flattenMesh(pm.triangles, pm.triangleCount, nodes, nn, idx, ni, fm);
+            if (rc == PT_OK && fm.hasBvh) {
+                G.hostNodeStart = (int)allHostNodes.size();
+                G.hostIndexStart = (int)allHostIndices.size();
+                allHostNodes.insert(allHostNodes.end(), nodes, nodes + nn);
+                allHostIndices.insert(allHostIndices.end(), idx, idx + ni);
+            }
             if (built) pt_bvh_free(built);
             if (rc != PT_OK) { pt_destroy(c); return rc; }
             G.nodeStart = (int)(allNodes.size() / 8);
@@ -1151,7 +1200,9 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
             allLeafOfOrig.insert(allLeafOfOrig.end(), fm.leafOfOrig.begin(), fm.leafOfOrig.end());
         }
     }
-    float4 *dNodes, *dHot, *dCold, *dBox; int* dLeaf; DGeom* dGeoms; PtMaterial* dMats;
+    float4 *dNodes, *dHot, *dCold, *dBox; int* dLeaf; DGeom* dGeoms; PtMaterial* dMats; PtBvhNode* dHostNodes; int32_t* dHostIdx;
+    TRY_RC(devUpload(c, &dHostNodes, allHostNodes.data(), allHostNodes.size()));
+    TRY_RC(devUpload(c, &dHostIdx, allHostIndices.data(), allHostIndices.size()));
     TRY_RC(devUpload(c, &dNodes, allNodes.data(), allNodes.size()));
     TRY_RC(devUpload(c, &dHot, allHot.data(), allHot.size()));
     TRY_RC(devUpload(c, &dCold, allCold.data(), allCold.size()));
@@ -1202,7 +1253,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
 
     SceneView& V = c->view;
     V.cameraOrigin = 0; V.leanHits = 0; V.traceDepth = c->traceDepth; memcpy(V.camPos, c->cam.position, sizeof(V.camPos));     /* set per call in traceBatch */
-    V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.triBox = dBox; V.leafOfOrig = dLeaf;
+    V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.triBox = dBox; V.leafOfOrig = dLeaf; V.hostNodes = dHostNodes; V.hostIndices = dHostIdx;
     V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond;
     V.numGeoms = d->geomCount; V.numMaterials = d->materialCount; V.numTextures = d->textureCount; V.numLights = (int)lights.size();
     V.envWidth = envOn ? d->env.width : 0; V.envHeight = envOn ? d->env.height : 0; V.envEnabled = envOn ? 1 : 0; V.useBvh = 1;
@@ -1234,9 +1285,9 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     return PT_OK;
 }
 
-static int traceBatchLaunch(PtContext* c, Batch bt)
+static int traceBatchLaunch(PtContext* c, Batch bt, int rowBase, bool deferSum)
 {
-    if (c->batch < 1 || bt.count < 1 || bt.count > c->batch) { pt_set_error("pt_trace: no path state for a group of %d iterations (allocated: %d)", bt.count, c->batch); return PT_EINVAL; }
+    if (c->batch < 1 || bt.count < 1 || rowBase < 0 || rowBase + bt.count > c->batch) { pt_set_error("pt_trace: no path state for a group of %d iterations (allocated: %d)", bt.count, c->batch); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     SceneView V = c->view;
@@ -1251,7 +1302,7 @@ static int traceBatchLaunch(PtContext* c, Batch bt)
     const bool meshes = V.numBvhMeshes > 0;
     /* a one-iteration call takes the next of `pipe` path-state rows and that row's streams; see PtContext::pipeDepth */
     const int pipe = std::min(std::min(c->pipeDepth, c->batch), kMaxStreamGroups);
-    const bool piped = bt.count == 1 && pipe > 1 && !c->timing && meshes;
+    const bool piped = bt.count == 1 && pipe > 1 && !c->timing && meshes && !deferSum && rowBase == 0;
     const int slot = piped ? (int)(c->pipeNext++ % (unsigned)pipe) : 0;
     /* Is the caller issuing calls ahead of the device?  Then up to `pipe` iterations are in flight: each traversal launch
      * takes 1/pipe of the machine's workgroup slots so that they run side by side (as the rows of a launch group do), and
@@ -1323,12 +1374,13 @@ static int traceBatchLaunch(PtContext* c, Batch bt)
     for (int g = 0; g < groups; ++g) {
         const int r0 = piped ? slot : (int)((long long)bt.count * g / groups), r1 = piped ? slot + 1 : (int)((long long)bt.count * (g + 1) / groups);
         const int sx = piped ? slot : g;        /* which streams and events */
+        const int rowAt = rowBase + r0;         /* first path-state row (and counter line) of this part */
         hipStream_t gs = (piped || groups > 1) ? c->groupStreams[sx] : s;
         if (groups > 1) HIP_TRY(hipStreamWaitEvent(gs, c->forkEvent, 0));
         Batch gb; gb.count = r1 - r0; gb.iterBase = bt.iterBase + (piped ? 0 : r0 * bt.iterStride); gb.iterStride = bt.iterStride;
-        PathState st = c->state.at(r0);
-        Queues q = c->queues.at(r0);
-        const size_t rowOff = (size_t)r0 * kCtrStride;
+        PathState st = c->state.at(rowAt);
+        Queues q = c->queues.at(rowAt);
+        const size_t rowOff = (size_t)rowAt * kCtrStride;
         { SpanGuard sg(c, ST_CAMERA, gs); ptl_camera(gs, V, c->cam, gb, c->traceDepth, st, q, closestCount + rowOff); }
         /* The shadow traversal of a bounce only settles colours and the image; compaction, the next closest-hit
          * stage and the sort do not look at either.  It therefore runs on a side stream next to them and is
@@ -1368,8 +1420,10 @@ static int traceBatchLaunch(PtContext* c, Batch bt)
             HIP_TRY(hipStreamWaitEvent(s, c->joinEvents[sx], 0));
         }
     }
-    ptl_finish(s, c->state.at(slot), c->queues.at(slot), bt, c->traceDepth, c->imageSum, c->dc, shadowCount + (size_t)slot * kCtrStride,
-               closestCount + (size_t)slot * kCtrStride, kMaxBatch);
+    const int finishRow = rowBase + slot;
+    ptl_finish(s, c->state.at(finishRow), c->queues.at(finishRow), bt, c->traceDepth, deferSum ? nullptr : c->imageSum, c->dc,
+               shadowCount + (size_t)finishRow * kCtrStride, closestCount + (size_t)finishRow * kCtrStride, kMaxBatch);
+    if (!deferSum) c->sumTouchedOnMain = true;
     if (piped) { HIP_TRY(hipEventRecord(c->slotFreeEvents[slot], s)); c->slotBusy[slot] = true; }
     if (tuning) {
         HIP_TRY(hipEventRecord(c->tuneEnd, s));
@@ -1405,9 +1459,10 @@ static int traceBatchLaunch(PtContext* c, Batch bt)
 /* A launch sequence that failed half-way leaves kernels on a row's streams that were never joined to the main stream,
  * and the bookkeeping of the pipelined rows half advanced: wait for everything the context has in flight and start the
  * rows afresh, so that a later pt_sync / pt_destroy / allocation cannot overtake work that still uses the path state. */
-static int traceBatch(PtContext* c, Batch bt)
+static int traceBatch(PtContext* c, Batch bt, int rowBase = 0, bool deferSum = false)
 {
-    const int rc = traceBatchLaunch(c, bt);
+    if (!deferSum) { c->aheadCur.valid = false; c->aheadNext.valid = false; }      /* rows rendered ahead are about to be overwritten */
+    const int rc = traceBatchLaunch(c, bt, rowBase, deferSum);
     if (rc != PT_OK && c->stream) {
         for (int g = 0; g < kMaxStreamGroups; ++g) {
             if (c->groupStreams[g]) (void)hipStreamSynchronize(c->groupStreams[g]);
@@ -1418,6 +1473,7 @@ static int traceBatch(PtContext* c, Batch bt)
         (void)hipGetLastError();
         c->pipeLast = -1;
         c->pipeBarrier = true;
+        c->aheadCur.valid = false; c->aheadNext.valid = false;
     }
     return rc;
 }
@@ -1449,6 +1505,8 @@ int pt_sync(PtContext* c)
     if (!c) { pt_set_error("pt_sync: null context"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->serveStream));       /* the last addition to the sum and the host copy behind it */
+    c->hostCopyPending = false;
     resolveSpans(c);
     return PT_OK;
 }
@@ -1457,9 +1515,122 @@ int pt_display(PtContext* c, int iter, uint8_t* dev_rgba)
 {
     if (!c || !dev_rgba || iter <= 0) { pt_set_error("pt_display: bad argument"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
-    ptl_display(c->stream, c->imageSum, c->numPixels, iter, dev_rgba);
+    /* while iterations are rendered ahead the sum is kept on the serve stream; the main stream is busy with the rows ahead */
+    ptl_display(c->aheadCur.valid ? c->serveStream : c->stream, c->imageSum, c->numPixels, iter, dev_rgba);
     HIP_TRY(hipGetLastError());
     return PT_OK;
+}
+
+/* the serve stream's next addition to the sum comes after everything the main stream has done to it so far */
+static int serveAfterMain(PtContext* c)
+{
+    if (!c->sumTouchedOnMain) return PT_OK;
+    HIP_TRY(hipEventRecord(c->sumReadyEvent, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->serveStream, c->sumReadyEvent, 0));
+    c->sumTouchedOnMain = false;
+    return PT_OK;
+}
+
+/* copy of the running sum into the bound host image, behind whatever the stream holds */
+static int queueHostCopy(PtContext* c, hipStream_t st)
+{
+    if (!c->hostImage) return PT_OK;
+    const size_t bytes = (size_t)c->numPixels * 3 * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(c->hostRegistered ? c->hostImage : c->hostStaging, c->imageSum, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(c->hostCopyDone, st));
+    c->hostCopyPending = true;
+    return PT_OK;
+}
+
+int pt_bind_host_image(PtContext* c, float* host_rgb)
+{
+    if (!c) { pt_set_error("pt_bind_host_image: null context"); return PT_EINVAL; }
+    int rc = pt_sync(c);
+    if (rc != PT_OK) return rc;
+    if (c->hostImage && c->hostRegistered) (void)hipHostUnregister(c->hostImage);
+    c->hostImage = nullptr;
+    c->hostRegistered = false;
+    if (!host_rgb) return PT_OK;
+    const size_t bytes = (size_t)c->numPixels * 3 * sizeof(float);
+    if (hipHostRegister(host_rgb, bytes, hipHostRegisterDefault) == hipSuccess) c->hostRegistered = true;
+    else {
+        (void)hipGetLastError();
+        if (!c->hostStaging) HIP_TRY(hipHostMalloc((void**)&c->hostStaging, bytes, hipHostMallocDefault));
+    }
+    c->hostImage = host_rgb;
+    return PT_OK;
+}
+
+int pt_host_image_wait(PtContext* c)
+{
+    if (!c) { pt_set_error("pt_host_image_wait: null context"); return PT_EINVAL; }
+    if (!c->hostImage || !c->hostCopyPending) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->hostCopyDone));
+    if (!c->hostRegistered) memcpy(c->hostImage, c->hostStaging, (size_t)c->numPixels * 3 * sizeof(float));
+    c->hostCopyPending = false;
+    return PT_OK;
+}
+
+int pt_trace_lookahead(PtContext* c, int iter, int ahead, int iter_last)
+{
+    if (!c || ahead < 1) { pt_set_error("pt_trace_lookahead: bad argument"); return PT_EINVAL; }
+    if (c->batch < 1) { pt_set_error("pt_trace_lookahead: no path state is allocated"); return PT_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int B = std::min(ahead, c->batch / 2);
+    if (B < 2) {
+        /* no room to render ahead: one iteration, as pt_trace does it, then the host copy */
+        Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
+        int rc = traceBatch(c, bt);
+        if (rc != PT_OK) return rc;
+        return queueHostCopy(c, c->stream);
+    }
+    auto launch = [&](PtContext::AheadGroup& g, int base, int rowBase) -> int {
+        int count = B;
+        if (iter_last > 0) count = std::min(count, iter_last - base + 1);
+        g.valid = false;
+        if (count < 1) return PT_OK;
+        Batch bt; bt.count = count; bt.iterBase = base; bt.iterStride = 1;
+        int rc = traceBatch(c, bt, rowBase, true);
+        if (rc != PT_OK) return rc;
+        HIP_TRY(hipEventRecord(g.done, c->stream));
+        g.base = base; g.count = count; g.rowBase = rowBase; g.valid = true;
+        return PT_OK;
+    };
+    /* before anything of this call reaches the main stream: the serve stream's additions come after what the main
+     * stream has done to the sum up to here (a clear, an upload, iterations added by pt_trace) */
+    {
+        int rc0 = serveAfterMain(c);
+        if (rc0 != PT_OK) return rc0;
+    }
+    PtContext::AheadGroup& cur = c->aheadCur;
+    PtContext::AheadGroup& next = c->aheadNext;
+    if (!(cur.valid && iter == cur.base + c->aheadServed && c->aheadServed < cur.count)) {
+        if (next.valid && iter == next.base) {
+            std::swap(cur, next);                       /* the group rendered meanwhile; its events travel with it */
+            next.valid = false;
+        } else {
+            /* not the iteration that was expected: whatever was rendered ahead is dropped */
+            next.valid = false;
+            int rc = launch(cur, iter, 0);
+            if (rc != PT_OK) return rc;
+            if (!cur.valid) { pt_set_error("pt_trace_lookahead: iteration %d lies beyond the last one (%d)", iter, iter_last); return PT_EINVAL; }
+        }
+        c->aheadServed = 0;
+    }
+    /* keep the device rendering: the group after this one goes onto the other half of the rows, whose contributions
+     * have all joined the sum (the main stream waited for each of them) */
+    if (!next.valid) {
+        int rc = launch(next, cur.base + cur.count, cur.rowBase == 0 ? B : 0);
+        if (rc != PT_OK) return rc;
+    }
+    if (c->aheadServed == 0) HIP_TRY(hipStreamWaitEvent(c->serveStream, cur.done, 0));
+    ptl_accumulate(c->serveStream, c->state.at(cur.rowBase + c->aheadServed), 1, c->imageSum);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->servedEvent, c->serveStream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->servedEvent, 0));
+    c->aheadServed++;
+    return queueHostCopy(c, c->serveStream);
 }
 
 int pt_download(PtContext* c, float* host_rgb)
@@ -1478,6 +1649,7 @@ int pt_bind_image(PtContext* c, float* dev_rgb)
     if (rc != PT_OK) return rc;
     c->imageSum = dev_rgb ? dev_rgb : c->imageOwned;
     c->ownImage = dev_rgb == nullptr;
+    c->sumTouchedOnMain = true;
     return PT_OK;
 }
 
@@ -1487,6 +1659,7 @@ int pt_upload_image(PtContext* c, const float* host_rgb)
     int rc = pt_sync(c);
     if (rc != PT_OK) return rc;
     HIP_TRY(hipMemcpy(c->imageSum, host_rgb, (size_t)c->numPixels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    c->sumTouchedOnMain = true;
     return PT_OK;
 }
 
@@ -1495,12 +1668,14 @@ int pt_clear(PtContext* c)
     if (!c) { pt_set_error("pt_clear: null context"); return PT_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->imageSum, 0, (size_t)c->numPixels * 3 * sizeof(float), c->stream));
+    c->sumTouchedOnMain = true;
     return PT_OK;
 }
 
 int pt_set_option(PtContext* c, int option, int value)
 {
     if (!c) { pt_set_error("pt_set_option: null context"); return PT_EINVAL; }
+    c->aheadCur.valid = false; c->aheadNext.valid = false;      /* rows rendered ahead were made under the old settings */
     switch (option) {
     case PT_OPT_MATERIAL_SORT: c->sortOn = value ? 1 : 0; break;
     case PT_OPT_USE_BVH: c->useBvh = value ? 1 : 0; break;
@@ -1569,6 +1744,7 @@ int pt_stats(PtContext* c, PtStats* out)
     out->tracedRays = h.workItems[0]; out->shadowRays = h.workItems[1];
     out->boxesTested = h.trav[0][3] + h.trav[1][3]; out->shadeBoxesTested = h.trav[1][3];
     out->maxStackDepth = std::max(h.maxStack[0], h.maxStack[1]); out->ldsStackEntries = kLdsStack;
+    out->referenceOrderWalks = h.refWalks;
     return PT_OK;
 }
 

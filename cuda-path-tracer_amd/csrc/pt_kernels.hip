@@ -62,7 +62,7 @@ PT_DEV int blockAppendIndex(bool flag, uint32_t* counter, int* s_tmp)
 PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 {
     /* one atomic per wave and counter */
-    unsigned n = c.nodes, t = c.tris, h = c.meshHits, b = c.boxes;
+    unsigned n = c.nodes, t = c.tris, h = c.meshHits, b = c.boxes, rw = c.refWalks;
     atomicMax(&dc->maxNodes[stage], n);
     atomicMax(&dc->maxTris[stage], t);
     atomicMax(&dc->maxStack[stage], c.maxSp);
@@ -71,12 +71,14 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
         t += __shfl_down(t, off);
         h += __shfl_down(h, off);
         b += __shfl_down(b, off);
+        rw += __shfl_down(rw, off);
     }
     if (laneId() == 0) {
         if (n) atomicAdd(&dc->trav[stage][0], (unsigned long long)n);
         if (t) atomicAdd(&dc->trav[stage][1], (unsigned long long)t);
         if (h) atomicAdd(&dc->trav[stage][2], (unsigned long long)h);
         if (b) atomicAdd(&dc->trav[stage][3], (unsigned long long)b);
+        if (rw) atomicAdd(&dc->refWalks, (unsigned long long)rw);
     }
 }
 
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     int shSlot = 0;             /* shadow mode: queue position of the lane's ray (its colour record is read when the verdict is in) */
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0; cnt.refWalks = 0;
     unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
     unsigned long long tStart = 0, tDry = 0;
     if (COUNT && MODE == TRACE_CLOSEST) {
@@ -258,9 +260,10 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
         if (__ballot(trav) == 0 || __builtin_popcountll(idle) >= kRefillThreshold) {
             /* epilogues and refills run together for all idle lanes */
             bool fetch = !trav && !exhausted;
-            if (done && travRecheck(S, tv)) { trav = true; done = false; fetch = false; }
             if (done) {
                 const DGeom& g = S.geoms[gi];
+                /* the rare ray whose closest hit depends on the order the reference visits its leaves in */
+                if (!travCertain(S, tv)) { travReference(S, g, tv, ovRef); if (COUNT) cnt.refWalks++; }
                 F3 nn; F2 uv; int mat = 0, tri = -1;
                 float t = travFinish(S, g, r, tv, false, nn, uv, mat, tri);
                 if (COUNT && tv.best >= 0) cnt.meshHits++;
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
     int vb = (int)blockIdx.x;
     if ((uint32_t)(vb * kBlock) >= n) return;
     const int numBuckets = S.numBuckets;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0; cnt.refWalks = 0;
     do {
         const int slot = vb * kBlock + tid;
         if (sortOn) {
@@ -594,7 +597,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     /* sorted order: the misses are the last bucket, and its first slot is the scanned histogram entry of that bucket's
      * first workgroup — their hit records (distance -1, nothing else read) are not fetched */
     const uint32_t missStart = sortOn ? (uint32_t)q.blockHist[(size_t)(S.numBuckets - 1) * q.numBlocks] : 0xffffffffu;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0; cnt.refWalks = 0;
     do {
         const int slot = vb * kBlock + tid;
         const bool active = (uint32_t)slot < n;
@@ -950,11 +953,22 @@ void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn)
     hipLaunchKernelGGL(k_compact_scatter, slotGrid(q, bt), dim3(kBlock), 0, s, q, bounce, sortOn);
     if (!sortOn) hipLaunchKernelGGL(k_copy_queue, slotGrid(q, bt), dim3(kBlock), 0, s, q, bounce);
 }
+/* image += the contribution images of `rows` consecutive rows starting at st's, in row order */
+void ptl_accumulate(hipStream_t s, PathState st, int rows, float* image)
+{
+    const size_t n3 = 3 * st.numPixels;
+    if (n3 % 4 == 0 && (((uintptr_t)image | (uintptr_t)st.image) & 15u) == 0)
+        hipLaunchKernelGGL(k_accumulate4, dim3(gridFor((long long)(n3 / 4))), dim3(kBlock), 0, s, (float4*)image, (float4*)st.image, n3 / 4, rows);
+    else
+        hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, rows);
+}
+/* image == nullptr: the rows' contribution images are left for a later ptl_accumulate */
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride)
 {
     hipLaunchKernelGGL(k_final_gather, slotGrid(q, bt), dim3(kBlock), 0, s, st, q, depth);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, q, depth, bt.count, (DevCounters*)dc, shadowCounts, closestCounts, rowStride);
+    if (!image) return;
     const size_t n3 = 3 * st.numPixels;
     if (n3 % 4 == 0 && (((uintptr_t)image | (uintptr_t)st.image) & 15u) == 0)
         hipLaunchKernelGGL(k_accumulate4, dim3(gridFor((long long)(n3 / 4))), dim3(kBlock), 0, s, (float4*)image, (float4*)st.image, n3 / 4, bt.count);

@@ -51,9 +51,9 @@ constexpr int kMaxBuckets = 256;     /* material ids + the miss bucket handled b
 
 struct DGeom {
     int type, materialid, nodeStart, triStart;
-    int triCount, hasBvh, meshIndex, pad0;
+    int triCount, hasBvh, meshIndex, hostNodeStart;     /* hostNodeStart / hostIndexStart: this mesh's part of SceneView::hostNodes / hostIndices */
     float T[16], I[16], IT[16];
-    float translation[3], pad1;
+    float translation[3]; int hostIndexStart;
     float scale[3], pad2;
     /* BVH meshes: world-space box around the transformed root box, padded by a percent of its size.
      * A ray that misses it by the plain slab test cannot pass any leaf box of the mesh. */
@@ -73,6 +73,8 @@ struct SceneView {
     const float4* triCold;
     const float4* triBox;       /* 2 per leaf-order triangle: min, max of its leaf in the host BVH; a hit counts only if the ray passes that box */
     const int* leafOfOrig;
+    const PtBvhNode* hostNodes; /* the host BVHs as built (40-byte binary nodes, src/bvh.h:55-65) and their triangle index arrays: walked only by */
+    const int* hostIndices;     /* travReference, for the rare ray whose result depends on the reference's own visiting order */
     const DTexture* textures;
     const DLight* lights;
     const float* envData;
@@ -202,6 +204,7 @@ struct DevCounters {
     unsigned long long pathBounces;
     unsigned long long trav[2][4];      /* [0] intersect stage, [1] shade stage: nodes, triangles, mesh hits, child boxes */
     unsigned long long workItems[2];    /* rays handed to the traversal kernel: closest-hit, shadow */
+    unsigned long long refWalks;        /* mesh walks repeated in the reference's own visiting order (travReference) */
     unsigned maxNodes[2], maxTris[2];   /* per-ray maxima of the counters (tail diagnosis) */
     unsigned maxStack[2];               /* deepest traversal stack any ray reached, per stage (entries; beyond kLdsStack they live in private memory) */
     unsigned maxWaveIters[2];           /* most loop iterations any wave of a traversal launch made (the launch's critical path) */
@@ -212,7 +215,7 @@ struct DevCounters {
     uint32_t liveMax[PT_MAX_DEPTH + 2]; /* per bounce, the largest live count over the rows of the last launch group */
 };
 
-struct TravCounters { uint32_t nodes, tris, meshHits, boxes, maxSp; };
+struct TravCounters { uint32_t nodes, tris, meshHits, boxes, maxSp, refWalks; };
 
 constexpr float kPI = 3.1415926535897932384626422832795028841971f;
 constexpr float kTWO_PI = 6.2831853071795864769252867665590057683943f;
@@ -336,7 +339,7 @@ struct MeshTrav {
     F3 lo, ld, invDir;          /* ray in the mesh's object space */
     float closestT;
     int best, bestRank;
-    F3 bary;                    /* .y, .z: barycentrics of the closest hit; .x: non-zero on the second, checking walk of a ray (see passesHostLeafBox) */
+    F3 bary;                    /* .y, .z: barycentrics of the closest hit; .x: smallest distance of any OTHER triangle hit the walk has seen (see travCertain) */
     int sp, ref;
     int nodeStart, triStart;    /* of the mesh being walked, kept in registers: a per-step reload from the geom
                                    record would put one more dependent memory access in front of every node fetch */
@@ -354,7 +357,7 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.closestT = 3.402823466e+38f;
     tv.best = -1;
     tv.bestRank = 0x7fffffff;
-    tv.bary = f3(0.0f);
+    tv.bary = f3(3.402823466e+38f, 0.0f, 0.0f);
     tv.sp = 0;
     tv.ref = 0;
     tv.nodeStart = g.nodeStart;
@@ -390,38 +393,82 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
 constexpr float kBoxSlack = 3.0517578125e-05f;
 PT_DEV float slackFar(float t) { return __builtin_fmaf(__builtin_fabsf(t), kBoxSlack, t); }
 
-/* intersectAABB (src/intersections.cu:248-266) on the box of the host-BVH leaf that holds leaf-order triangle `tri`,
- * in the reference's arithmetic (component-wise min / max as compare-and-select, NaN behaviour included).  The
- * reference tests a leaf's triangles only when this holds, so a hit found by walking other boxes counts only then.
- * A hit that fails is a rounding accident at the rim of a leaf box (the triangle lies inside it), so the walk does not
- * look at the box per hit: the closest hit is checked once when the walk is over (travRecheck), and only if that
- * fails is the ray walked again with the check on every new closest hit (MeshTrav::bary.x set) — the closest of
- * the hits that pass. */
-PT_DEV bool passesHostLeafBox(const SceneView& S, const MeshTrav& tv, int tri)
+/* intersectAABB (src/intersections.cu:248-266) in the reference's arithmetic: component-wise min / max as compare-and-select
+ * (NaN behaviour included), the true reciprocal of the direction, infinities included. */
+PT_DEV bool refSlab(F3 bmin, F3 bmax, F3 lo, F3 invDir, float& tMin, float& tMax)
 {
-    const float4* b = S.triBox + 2 * ((size_t)tv.triStart + (size_t)tri);
-    const float4 bmin = b[0], bmax = b[1];
-    const F3 lo = tv.lo, invDir = 1.0f / tv.ld;       /* the true reciprocal, infinities included */
     float ax0 = (bmin.x - lo.x) * invDir.x, ax1 = (bmax.x - lo.x) * invDir.x;
     float ay0 = (bmin.y - lo.y) * invDir.y, ay1 = (bmax.y - lo.y) * invDir.y;
     float az0 = (bmin.z - lo.z) * invDir.z, az1 = (bmax.z - lo.z) * invDir.z;
-    float tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));
-    float tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));
+    tMin = selMax(selMax(selMin(ax0, ax1), selMin(ay0, ay1)), selMin(az0, az1));
+    tMax = selMin(selMin(selMax(ax0, ax1), selMax(ay0, ay1)), selMax(az0, az1));
     return tMax >= tMin && tMax >= 0.0f;
 }
 
-/* After a walk has ended: true if its closest hit is one the reference would not have looked at; the walk of this
- * mesh then starts over from the root, checking every new closest hit as it is found. */
-PT_DEV bool travRecheck(const SceneView& S, MeshTrav& tv)
+/* Is the closest hit G of a finished walk certainly the reference's answer?
+ *
+ * The walk has tested every triangle whose (padded) box the ray passes up to slackFar(distance of G), so G is the smallest
+ * distance over ALL triangles, the first-visited among equals.  The reference scans its leaves in its own order, tests a
+ * leaf's triangles only if the ray passes the leaf's box, and skips a node whose box is entered beyond the closest hit
+ * so far (src/intersections.cu:351-358).  G is the reference's answer whenever the reference cannot have skipped it:
+ *   - the ray passes the box of G's leaf in the reference's BVH (its ancestors' boxes then too: nested slab intervals
+ *     nest in IEEE arithmetic), and
+ *   - that box is entered no later than G's own distance — every "closest so far" the reference ever holds is the
+ *     distance of some triangle hit, hence >= G's, hence >= the entry distance of every box around G — or, when rounding
+ *     puts the entry a little beyond G's distance (a triangle that lies in a face of its leaf's box; a hit a hair outside
+ *     the triangle's rim), no OTHER triangle was hit before that entry distance: then "closest so far" was never
+ *     below it while G's leaf waited.  The walk knows the smallest other hit distance (bary.x) for everything it
+ *     tested, which covers all distances up to slackFar(G's).
+ * Otherwise the outcome depends on the order in which the reference visits its leaves, and travReference repeats
+ * that order. */
+PT_DEV bool travCertain(const SceneView& S, const MeshTrav& tv)
 {
-    if (tv.best < 0 || tv.bary.x != 0.0f || passesHostLeafBox(S, tv, tv.best)) return false;
-    tv.closestT = 3.402823466e+38f;
-    tv.best = -1;
-    tv.bestRank = 0x7fffffff;
-    tv.bary.x = 1.0f;
-    tv.sp = 0;
-    tv.ref = 0;
-    return true;
+    if (tv.best < 0) return true;
+    const float4* b = S.triBox + 2 * ((size_t)tv.triStart + (size_t)tv.best);
+    const float4 bmin = b[0], bmax = b[1];
+    float tMin, tMax;
+    if (!refSlab(f3(bmin.x, bmin.y, bmin.z), f3(bmax.x, bmax.y, bmax.z), tv.lo, 1.0f / tv.ld, tMin, tMax)) return false;
+    if (!(tMin > tv.closestT)) return true;
+    return !(tMin > slackFar(tv.closestT)) && !(tv.bary.x < tMin);
+}
+
+/* meshIntersectionTestBVH's own loop (src/intersections.cu:331-386) over the host BVH as built: explicit stack of 64
+ * node indices (a push beyond it is dropped, as there), left child pushed first and so the right one visited first, a
+ * node skipped when the ray misses its box or enters it beyond the closest hit so far, strict '<' between triangles.
+ * Same slab and triangle arithmetic as everywhere else; the triangle records are reached through the leaf-order map.
+ * stack: 64 ints of private memory. */
+PT_DEV void travReference(const SceneView& S, const DGeom& g, MeshTrav& tv, int* stack)
+{
+    const PtBvhNode* nodes = S.hostNodes + g.hostNodeStart;
+    const int* indices = S.hostIndices + g.hostIndexStart;
+    const float4* hot = S.triHot + 3 * (size_t)g.triStart;
+    const F3 lo = tv.lo, ld = tv.ld, invDir = 1.0f / tv.ld;
+    float closestT = 3.402823466e+38f;
+    int best = -1;
+    float bu = 0.0f, bv = 0.0f;
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const PtBvhNode nd = nodes[stack[--sp]];
+        float tMin, tMax;
+        if (!refSlab(f3(nd.bmin[0], nd.bmin[1], nd.bmin[2]), f3(nd.bmax[0], nd.bmax[1], nd.bmax[2]), lo, invDir, tMin, tMax)) continue;
+        if (tMin > closestT) continue;
+        if (nd.leftChild == -1) {
+            for (int i = 0; i < nd.triangleCount; ++i) {
+                const int slot = S.leafOfOrig[g.triStart + indices[nd.triangleStart + i]];
+                F3 bary;
+                const float tt = hitTriangle(hot + 3 * (size_t)slot, lo, ld, bary);
+                if (tt > 0.0f && tt < closestT) { closestT = tt; best = slot; bu = bary.y; bv = bary.z; }
+            }
+        } else {
+            if (nd.leftChild >= 0 && sp < 64) stack[sp++] = nd.leftChild;
+            if (nd.rightChild >= 0 && sp < 64) stack[sp++] = nd.rightChild;
+        }
+    }
+    tv.closestT = closestT;
+    tv.best = best;
+    tv.bary.y = bu;
+    tv.bary.z = bv;
 }
 
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
@@ -524,12 +571,14 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
             F3 bary;
             float tt = hitTriangleRec(ra, rb, rc, tv.lo, tv.ld, bary);
             if (COUNT) cnt.tris++;
-            if (tt > 0.0f && !(tt > tv.closestT)) {
-                int rank = __float_as_int(rc.z);
-                if (tt < tv.closestT || rank < tv.bestRank) {
-                    /* a new closest hit — if the reference would have looked at this triangle at all */
-                    if (tv.bary.x == 0.0f || passesHostLeafBox(S, tv, first + i)) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
-                }
+            if (tt > 0.0f) {
+                if (!(tt > tv.closestT)) {
+                    const int rank = __float_as_int(rc.z);
+                    const bool closer = tt < tv.closestT;
+                    /* the runner-up: the hit this one displaces, or this one when it only ties */
+                    tv.bary.x = closer ? tv.closestT : tt;
+                    if (closer || rank < tv.bestRank) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
+                } else if (tt < tv.bary.x) tv.bary.x = tt;
             }
             ra = na; rb = nb; rc = nc;
         }

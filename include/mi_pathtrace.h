@@ -202,6 +202,8 @@ typedef struct PtStats {
     uint64_t shadeBoxesTested;   /* the shadow mode's share                            */
     uint32_t maxStackDepth;      /* deepest traversal stack any ray reached (counters on) */
     uint32_t ldsStackEntries;    /* entries per ray held in LDS; deeper ones spill to private memory */
+    uint64_t referenceOrderWalks; /* mesh walks repeated in the reference's own leaf order because the closest hit
+                                     depended on it (counters on) */
 } PtStats;
 
 /* Closest-hit record for the fixed-ray-set parity hook. */
@@ -262,6 +264,26 @@ int pt_trace(PtContext* ctx, int iter);
  * pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, n) with n in 1..8, or PT_STREAMS=n in the
  * environment when the context is created; no trial runs then, and no waits. */
 int pt_trace_range(PtContext* ctx, int iter_begin, int iter_end, int iter_stride);
+
+/* pathtrace(pbo, frame, iteration) called once per frame with iteration = 1, 2, 3, ... (src/main.cpp:812-837), at the
+ * rate of launch groups.  The call has pt_trace's meaning — when it returns, iteration `iter` has been issued and the
+ * running sum will hold every iteration asked for so far, added in call order, bit for bit what pt_trace gives — but the
+ * first call renders iterations iter .. iter+ahead-1 in one launch group and starts the group after it, and the calls
+ * that follow only add the row that was rendered for them while the device renders the rows further ahead.  Needs
+ * PT_OPT_BATCH >= 2 * ahead (two halves of the path-state rows take turns); with less, ahead shrinks to half the rows,
+ * down to plain pt_trace.  iter_last > 0 names the last iteration that will ever be asked for: nothing beyond it is
+ * rendered.  A call that is not the expected next iteration, any pt_set_option, pt_trace or pt_trace_range drops what
+ * was rendered ahead (correct, only slower).  pt_sync / pt_download / pt_stats wait for the rows ahead as well. */
+int pt_trace_lookahead(PtContext* ctx, int iter, int ahead, int iter_last);
+
+/* cudaMemcpy(hst_scene->state.image, dev_image) after every iteration (src/pathtrace.cu:2913-2917), without a wait in
+ * it: host_rgb (W*H*3 floats that the caller keeps alive) is page-locked in place — or, if the runtime refuses,
+ * reached through a pinned buffer of the library's — and every pt_trace_lookahead call from then on ends by queueing a
+ * copy of the running sum into it, ordered behind that call's addition.  pt_host_image_wait blocks until the copy
+ * of the most recent call has landed; a caller that reads the host image after every call (the reference's saveImage
+ * only does after the last) waits after every call.  NULL unbinds. */
+int pt_bind_host_image(PtContext* ctx, float* host_rgb);
+int pt_host_image_wait(PtContext* ctx);
 
 /* sendImageToPBO (src/pathtrace.cu:145-166): sum/iter -> RGBA8 into a DEVICE
  * buffer of W*H*4 bytes. */

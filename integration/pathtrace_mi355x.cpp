@@ -23,6 +23,7 @@ static_assert(sizeof(Material) == sizeof(PtMaterial) && sizeof(Triangle) == size
 static PtContext* ctx = nullptr;
 static Scene* hst_scene = nullptr;
 static GuiDataContainer* guiData = nullptr;
+static int lookahead = 0;               /* iterations rendered ahead of the calls (0: one per call) */
 
 static void die(const char* what)
 {
@@ -107,18 +108,28 @@ void pathtraceInit(Scene* scene)
     d.iterations = (int32_t)scene->state.iterations;
     if (pt_create(&d, /* device */ 0, &ctx) != PT_OK) die("pathtraceInit");
     if (pt_set_option(ctx, PT_OPT_MATERIAL_SORT, MATERIAL_SORTING) != PT_OK) die("pathtraceInit");
+    /* runCuda calls pathtrace(pbo, 0, ++iteration) once per frame (src/main.cpp:812-837).  The iterations behind the one
+     * asked for are rendered ahead in the same launch group, 64 at a time (PT_LOOKAHEAD), and handed out one per call:
+     * two halves of the path-state rows take turns, so rows for twice as many iterations are allocated, fewer when the
+     * device cannot hold them.  One stream per launch group, so that no call waits inside the library. */
+    const char* aheadEnv = getenv("PT_LOOKAHEAD");
+    lookahead = 0;
+    for (int a = aheadEnv ? atoi(aheadEnv) : 64; a >= 2; a /= 2)
+        if (pt_set_option(ctx, PT_OPT_BATCH, 2 * (a > 256 ? 256 : a)) == PT_OK) { lookahead = a > 256 ? 256 : a; break; }
+    if (pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, 1) != PT_OK) die("pathtraceInit");
+    /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): its memory is
+     * page-locked where it lies, so the copy runs asynchronously at the bus rate */
+    if (pt_bind_host_image(ctx, reinterpret_cast<float*>(scene->state.image.data())) != PT_OK) die("pathtraceInit");
 }
 
 void pathtrace(uchar4* pbo, int /* frame */, int iter)
 {
     if (!ctx) { fprintf(stderr, "pathtrace: pathtraceInit has not been called\n"); exit(EXIT_FAILURE); }
-    if (pt_trace(ctx, iter) != PT_OK) die("pathtrace");
+    if (guiData) guiData->TracedDepth = hst_scene->state.traceDepth;        /* src/pathtrace.cu:2712-2715 */
+    const int last = (int)hst_scene->state.iterations;                      /* the loop saves and exits there (src/main.cpp:831-837) */
+    if (pt_trace_lookahead(ctx, iter, lookahead > 0 ? lookahead : 1, iter <= last ? last : 0) != PT_OK) die("pathtrace");
     if (pbo && pt_display(ctx, iter, reinterpret_cast<uint8_t*>(pbo)) != PT_OK) die("pathtrace");      /* pbo: a device pointer, as the GL interop map yields */
-    /* the running sum goes back to the host after every iteration, as at src/pathtrace.cu:2913-2917 */
-    if (pt_download(ctx, reinterpret_cast<float*>(hst_scene->state.image.data())) != PT_OK) die("pathtrace");
-    if (guiData) {
-        PtStats s;
-        if (pt_stats(ctx, &s) != PT_OK) die("pathtrace");
-        guiData->TracedDepth = (int)s.lastDepth;        /* src/pathtrace.cu:2712-2715 */
-    }
+    /* the running sum is back on the host when the call returns, as after the blocking copy at src/pathtrace.cu:2913-2917
+     * (a maintainer who only reads the image in saveImage moves this wait there) */
+    if (pt_host_image_wait(ctx) != PT_OK) die("pathtrace");
 }

@@ -10,6 +10,7 @@
 #include "pathtrace.h"
 #include "scene.h"
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -60,14 +61,27 @@ int main(int argc, char** argv)
     InitDataContainer(&gui);
     pathtraceFree();                                    /* src/main.cpp:814 */
     pathtraceInit(scene);
-    for (int it = 1; it <= iterations; ++it) pathtrace(nullptr, 0, it);
+    /* the loop of runCuda (src/main.cpp:812-837): one call per frame; wall time per call, the first call (which also
+     * carries the one-off set-up of the first launch groups) apart */
+    double firstMs = 0.0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int it = 1; it <= iterations; ++it) {
+        pathtrace(nullptr, 0, it);
+        if (it == 1) {
+            auto t1 = std::chrono::steady_clock::now();
+            firstMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            t0 = t1;
+        }
+    }
+    const double restMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     FILE* f = fopen(argv[3], "wb");
     if (!f) { fprintf(stderr, "cannot write %s\n", argv[3]); return 2; }
     int32_t wh[2] = { cam.resolution.x, cam.resolution.y };
     fwrite(wh, 4, 2, f);
     fwrite(scene->state.image.data(), 12, scene->state.image.size(), f);
     fclose(f);
-    fprintf(stderr, "ref_render: %d iterations, traced depth %d\n", iterations, gui.TracedDepth);
+    fprintf(stderr, "ref_render: %d iterations at %dx%d, traced depth %d, first pathtrace() call %.3f ms, the other %d calls %.4f ms each (host image up to date after every call)\n",
+            iterations, cam.resolution.x, cam.resolution.y, gui.TracedDepth, firstMs, iterations - 1, iterations > 1 ? restMs / (iterations - 1) : 0.0);
     pathtraceFree();
     return 0;
 }

@@ -430,15 +430,19 @@ def test_reference_loader_through_maintainer_shim_renders_the_same_image(pt, sce
     out = tmp_path / "sum.bin"
     env = dict(os.environ)
     env.pop("LD_BIND_NOW", None)
-    r = subprocess.run([render, str(p), "3", str(out), "96", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    # 40 calls of pathtrace(), iterations rendered 8 ahead: five launch groups take turns on the two halves of the rows
+    env["PT_LOOKAHEAD"] = "8"
+    calls = 40
+    r = subprocess.run([render, str(p), str(calls), str(out), "96", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=180)
     assert r.returncode == 0, r.stderr.decode()[-500:]
+    print(r.stderr.decode().strip().splitlines()[-1])
     raw = out.read_bytes()
     w, h = np.frombuffer(raw[:8], np.int32)
     theirs = np.frombuffer(raw[8:], np.float32).reshape(h, w, 3)
     sc = pt.Scene(p)
     sc.set_resolution(96, 64)
     tr = pt.Tracer(sc)
-    for it in (1, 2, 3):
+    for it in range(1, calls + 1):
         tr.trace(it)
     mine = tr.image()
     assert (w, h) == (96, 64) and float(mine.sum()) > 0
