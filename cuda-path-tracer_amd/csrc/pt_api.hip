@@ -45,7 +45,7 @@ static std::atomic<unsigned long long> g_resourceCalls{0};
 void ptl_camera(hipStream_t s, const SceneView& S, const PtCamera& cam, Batch bt, int depth, PathState st, Queues q, uint32_t* traceCount);
 void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, uint32_t* workCount);
 void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
-               uint32_t* fetchCtr, const uint32_t* workCount, void* dc, int share = 1);
+               uint32_t* fetchCtr, const uint32_t* workCount, uint32_t* refCount, void* dc, int share = 1);
 void ptl_prims(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count, void* dc, bool sparse);
 void ptl_sort(hipStream_t s, Queues q, Batch bt, int bounce, int numBuckets);
 void ptl_shade(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, int sortOn, bool count,
@@ -80,12 +80,11 @@ constexpr int kMaxStreamGroups = 8;
 constexpr int kTuneShapes = 4;          /* launch shapes tried: 1, 2, 3 streams (1 with the shadow traversal on a side stream), then one stream and nothing beside it */
 constexpr int kTuneMinRows = 12;        /* smaller launch groups stay on one stream */
 /* device work counters, zeroed before every launch group: [section][bounce][batch row] with sections
- * 0 = next entry of the closest-hit traversal, 1 = next entry of the shadow traversal, 2 = shadow queue length,
+ * 0 = closest-hit rays left for k_refwalk, 1 = shadow rays left for k_refwalk, 2 = shadow queue length,
  * 3 = closest-hit work queue length */
 constexpr int kWorkCtrSection = (PT_MAX_DEPTH + 1) * kMaxBatch * kCtrStride;      /* one 128-byte line per counter */
 constexpr int kWorkCtrCount = 4 * kWorkCtrSection;
-/* sections 0 and 1 hold one line per (bounce, row) and are no longer used; the fetch counters proper are
- * [kind: closest, shadow][bounce][segment][row] in PtContext::fetchCtr (see kSegPitch) */
+/* the fetch counters of the traversal are [kind: closest, shadow][bounce][segment][row] in PtContext::fetchCtr (see kSegPitch) */
 static_assert(kMaxBatch == kCtrRows, "counter layout");
 constexpr size_t kFetchKind = (size_t)(PT_MAX_DEPTH + 1) * kFetchBouncePitch;
 constexpr size_t kFetchCtrCount = 2 * kFetchKind;
@@ -232,7 +231,7 @@ int allocBatchState(PtContext* c, int batch)
 {
     const size_t N = (size_t)c->numPixels, B = (size_t)batch;
     size_t freeB = 0, totalB = 0;
-    const size_t need = N * B * 195;
+    const size_t need = N * B * 203;
     const bool known = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
     if (known && need > totalB) {       /* cannot fit on this device at all: fail before anything is released */
         pt_set_error("path state for %d iterations at %d pixels needs about %zu MB, the device has %zu MB", batch, c->numPixels, need >> 20, totalB >> 20);
@@ -267,7 +266,7 @@ int allocBatchState(PtContext* c, int batch)
     }
     BA(P.hitB, N * B, false);
     BA(P.hitTri, N * B, false);
-    BA(P.shRec, N * B * 3, false); BA(P.traceQueue, N * B, false);
+    BA(P.shRec, N * B * 3, false); BA(P.traceQueue, N * B, false); BA(P.refList, N * B * 2, false);
     BA(P.image, N * B * 3, true);
     BA(Q.q0, N * B, false); BA(Q.q1, N * B, false); BA(Q.keys, N * B, false);
     BA(Q.blockHist, (size_t)Q.numBuckets * Q.numBlocks * B, false);
@@ -754,6 +753,37 @@ struct Flattener {
     }
 };
 
+/* The first `top` 4-wide nodes in breadth-first order get the numbers 0 .. top-1 (the root stays 0); the others keep their
+ * depth-first order behind them, which keeps a subtree's nodes close together in memory.  A traversal workgroup can then
+ * hold "nodes 0 .. k-1" in LDS for any k <= top and has the top levels of the tree. */
+void numberTopBreadthFirst(FlatMesh& fm, int top)
+{
+    const int n = (int)(fm.nodes.size() / 8);
+    if (n < 2) return;
+    auto childRef = [&](int node, int slot) { int r; float f = (&fm.nodes[8 * (size_t)node + 6].x)[slot]; memcpy(&r, &f, 4); return r; };
+    std::vector<int> order;                 /* breadth-first prefix */
+    order.push_back(0);
+    for (size_t at = 0; at < order.size() && (int)order.size() < top; ++at)
+        for (int s = 0; s < 4 && (int)order.size() < top; ++s) {
+            const int r = childRef(order[at], s);
+            if (r >= 0 && r != kEmptyRef && r < n) order.push_back(r);
+        }
+    std::vector<int> newId(n, -1);
+    for (size_t i = 0; i < order.size(); ++i) newId[order[i]] = (int)i;
+    int next = (int)order.size();
+    for (int i = 0; i < n; ++i) if (newId[i] < 0) newId[i] = next++;
+    std::vector<float4> out(fm.nodes.size());
+    for (int i = 0; i < n; ++i) {
+        float4* dst = &out[8 * (size_t)newId[i]];
+        for (int k = 0; k < 8; ++k) dst[k] = fm.nodes[8 * (size_t)i + k];
+        for (int s = 0; s < 4; ++s) {
+            const int r = childRef(i, s);
+            if (r >= 0 && r != kEmptyRef && r < n) (&dst[6].x)[s] = asF(newId[r]);
+        }
+    }
+    fm.nodes.swap(out);
+}
+
 int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nnodes, const int32_t* indices, int nidx,
                 FlatMesh& fm)
 {
@@ -905,6 +935,7 @@ int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nn
         pt_set_error("BVH too deep for the traversal stack (%d wide levels)", fm.depth4);
         return PT_ELIMIT;
     }
+    numberTopBreadthFirst(fm, 85);          /* root + three full levels */
     fm.hasBvh = true;
     return PT_OK;
 }
@@ -1261,6 +1292,9 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     V.numBuckets = d->materialCount + 1;
     V.numBvhMeshes = c->bvhMeshGeoms;
     V.packGeom = d->geomCount <= 32 ? 1 : 0;
+    /* nodes the traversal workgroups copy to LDS: the head of the node array, which is the breadth-first numbered top of
+     * the first mesh's tree (any node below that index is read from the copy, whichever mesh it belongs to) */
+    V.topCount = std::min<int>(kTopNodes, (int)(allNodes.size() / 8));
 
     /* ---- running sum, path state and queues */
     const size_t N = (size_t)c->numPixels;
@@ -1337,6 +1371,8 @@ static int traceBatchLaunch(PtContext* c, Batch bt, int rowBase, bool deferSum)
     }
     uint32_t* closestFetch = c->fetchCtr;
     uint32_t* shadowFetch = c->fetchCtr + kFetchKind;
+    uint32_t* closestRef = ctr;
+    uint32_t* shadowRef = ctr + kWorkCtrSection;
     uint32_t* shadowCount = ctr + 2 * kWorkCtrSection;
     uint32_t* closestCount = ctr + 3 * kWorkCtrSection;
     if (c->hintPending && hipEventQuery(c->hintEvent) == hipSuccess) {
@@ -1395,7 +1431,7 @@ static int traceBatchLaunch(PtContext* c, Batch bt, int rowBase, bool deferSum)
                 SpanGuard sg(c, ST_INTERSECT, gs);
                 if (meshes) {
                     SpanGuard t(c, ST_TRACE, gs);
-                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + (size_t)b * kFetchBouncePitch + rowOff, closestCount + row, c->dc, share);
+                    ptl_trace(gs, V, st, q, gb, b, false, count, closestFetch + (size_t)b * kFetchBouncePitch + rowOff, closestCount + row, closestRef + row, c->dc, share);
                 }
                 ptl_prims(gs, V, st, q, gb, b, c->sortOn, count, c->dc, sparseBounce(b));
             }
@@ -1408,7 +1444,7 @@ static int traceBatchLaunch(PtContext* c, Batch bt, int rowBase, bool deferSum)
                 if (meshes) {
                     if (side) { HIP_TRY(hipEventRecord(c->shadedEvents[sx], gs)); HIP_TRY(hipStreamWaitEvent(ss, c->shadedEvents[sx], 0)); }
                     SpanGuard t(c, ST_SHADOW_TRACE, ss);
-                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + (size_t)b * kFetchBouncePitch + rowOff, shadowCount + row, c->dc, share);
+                    ptl_trace(ss, V, st, q, gb, b, true, count, shadowFetch + (size_t)b * kFetchBouncePitch + rowOff, shadowCount + row, shadowRef + row, c->dc, share);
                     if (side) { HIP_TRY(hipEventRecord(c->shadowDoneEvents[sx], ss)); shadowOpen = true; }
                 }
             }
@@ -1784,13 +1820,14 @@ static int intersectStaged(PtContext* c, const float* origins, const float* dire
         if (e == hipSuccess) e = hipMemcpyAsync(dD, directions + 3 * (size_t)first, (size_t)m * 12, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(fetch, 0, (size_t)kFetchBouncePitch * sizeof(uint32_t), c->stream);     /* the eight counter lines of every row */
         if (e == hipSuccess) e = hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(uint32_t), c->stream);          /* k_refwalk's list length */
         if (e == hipSuccess) {
             Batch bt; bt.count = 1; bt.iterBase = 0; bt.iterStride = 0;
             c->pipeBarrier = true;      /* row 0 of the path state is used on the main stream */
             ptl_import_rays(c->stream, c->state, c->queues, dO, dD, m);
             if (V.numBvhMeshes > 0) {
                 { MaybeSpan g(c, ST_INTERSECT, spans); ptl_cull(c->stream, V, c->state, c->queues, bt, 0, ctr + 3 * kWorkCtrSection); }
-                { MaybeSpan g(c, ST_TRACE, spans); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, count, fetch, ctr + 3 * kWorkCtrSection, c->dc); }
+                { MaybeSpan g(c, ST_TRACE, spans); ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, count, fetch, ctr + 3 * kWorkCtrSection, ctr, c->dc); }
             }
             { MaybeSpan g(c, ST_INTERSECT, spans); ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, count, c->dc, false); }
             ptl_export_hits(c->stream, c->state, m, dH);
@@ -1856,9 +1893,10 @@ int pt_capture_gbuffer(PtContext* c, int iter, float* normals, float* albedo)
     Batch bt; bt.count = 1; bt.iterBase = iter; bt.iterStride = 1;
     HIP_TRY(hipMemsetAsync(fetch, 0, (size_t)kFetchBouncePitch * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(ctr + 3 * kWorkCtrSection, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(uint32_t), c->stream));
     c->pipeBarrier = true;      /* row 0 of the path state is used on the main stream */
     ptl_camera(c->stream, V, c->cam, bt, c->traceDepth, c->state, c->queues, V.numBvhMeshes > 0 ? ctr + 3 * kWorkCtrSection : nullptr);
-    if (V.numBvhMeshes > 0) ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, fetch, ctr + 3 * kWorkCtrSection, nullptr);
+    if (V.numBvhMeshes > 0) ptl_trace(c->stream, V, c->state, c->queues, bt, 0, false, false, fetch, ctr + 3 * kWorkCtrSection, ctr, nullptr);
     ptl_prims(c->stream, V, c->state, c->queues, bt, 0, 0, false, nullptr, false);
     ptl_gbuffer(c->stream, c->state, V.materials, (int)n, c->gNormals, c->gAlbedo);
     HIP_TRY(hipGetLastError());

@@ -62,7 +62,7 @@ PT_DEV int blockAppendIndex(bool flag, uint32_t* counter, int* s_tmp)
 PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
 {
     /* one atomic per wave and counter */
-    unsigned n = c.nodes, t = c.tris, h = c.meshHits, b = c.boxes, rw = c.refWalks;
+    unsigned n = c.nodes, t = c.tris, h = c.meshHits, b = c.boxes;
     atomicMax(&dc->maxNodes[stage], n);
     atomicMax(&dc->maxTris[stage], t);
     atomicMax(&dc->maxStack[stage], c.maxSp);
@@ -71,14 +71,12 @@ PT_DEV void flushCounters(const TravCounters& c, DevCounters* dc, int stage)
         t += __shfl_down(t, off);
         h += __shfl_down(h, off);
         b += __shfl_down(b, off);
-        rw += __shfl_down(rw, off);
     }
     if (laneId() == 0) {
         if (n) atomicAdd(&dc->trav[stage][0], (unsigned long long)n);
         if (t) atomicAdd(&dc->trav[stage][1], (unsigned long long)t);
         if (h) atomicAdd(&dc->trav[stage][2], (unsigned long long)h);
         if (b) atomicAdd(&dc->trav[stage][3], (unsigned long long)b);
-        if (rw) atomicAdd(&dc->refWalks, (unsigned long long)rw);
     }
 }
 
@@ -156,11 +154,14 @@ __global__ void __launch_bounds__(kBlock) k_camera(SceneView S, PtCamera cam, Ba
 #ifndef PT_REFILL
 #define PT_REFILL 24
 #endif
+/* Registers: the traversal kernel is held to 96 (five waves per SIMD by the register file) although its persistent grid
+ * only fills four — the room that leaves on every SIMD is what lets the kernels of other stages and streams (the shadow
+ * traversal of the previous bounce, the primitive stage, the sort) run beside it.  The shade kernel fits six. */
 #ifndef PT_TRACE_MINWAVES
-#define PT_TRACE_MINWAVES 4
+#define PT_TRACE_MINWAVES 5
 #endif
 #ifndef PT_SHADE_MINWAVES
-#define PT_SHADE_MINWAVES 5
+#define PT_SHADE_MINWAVES 6
 #endif
 #ifndef PT_LEAF_WAIT
 #define PT_LEAF_WAIT 20
@@ -206,11 +207,38 @@ __global__ void __launch_bounds__(kBlock) k_cull(SceneView S, PathState st, Queu
 }
 
 /* items: work queue entries [0, workCount[row]) */
+/* Settling a finished shadow ray (both traversal kernels): the path takes the colour of the unoccluded outcome if nothing
+ * blocked, and a path that has ended makes its one contribution to the iteration's image, which the shade stage held back. */
+PT_DEV void settleShadow(const PathState& st, int pix, int shSlot, bool blocked)
+{
+    float4 c = st.col[pix];
+    if (!blocked) {
+        float4 v = st.shRec[3 * (size_t)shSlot + 2];
+        c.x = v.x; c.y = v.y; c.z = v.z;
+        st.col[pix] = c;
+    }
+    if (__float_as_int(c.w) <= 0) {
+        /* the path's one contribution, see k_shade (nothing for a path that ended below zero) */
+        const bool counts = __float_as_int(c.w) == 0;
+        float* im = st.image + 3 * (size_t)pix;
+        im[0] = counts ? c.x : 0.0f; im[1] = counts ? c.y : 0.0f; im[2] = counts ? c.z : 0.0f;
+    }
+}
+
+/* what the closest-hit traversal hands to the primitive stage for a ray: (distance, barycentric u, v, leaf-order triangle [+ geom]) */
+PT_DEV void writeMeshHit(const SceneView& S, const PathState& st, int pix, int bounce, const Hit& best)
+{
+    const int triWord = S.packGeom ? (best.tri | (best.geom << 26)) : best.tri;
+    hitARef(S, st, pix, bounce) = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(triWord));
+    if (!S.packGeom && best.t > 0.0f) st.hitTri[pix] = best.geom;
+}
+
 template <int MODE, bool COUNT>
 __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S, PathState st, Queues q, int bounce,
-                                                                     uint32_t* fetchCtr, const uint32_t* workCount, DevCounters* dc)
+                                                                     uint32_t* fetchCtr, const uint32_t* workCount, uint32_t* refCount, DevCounters* dc)
 {
     __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ float4 s_top[kTopNodes > 0 ? kTopNodes * 8 : 1];
     const int tid = threadIdx.x;
     const int lane = laneId();
     st = st.at(blockIdx.y);
@@ -219,6 +247,11 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     /* a short queue does not need every workgroup of the row: those beyond one ray per lane leave at once, without
      * touching the counters (late bounces hold a few thousand rays per row) */
     if ((uint32_t)blockIdx.x * kBlock >= n) return;
+    if (kTopNodes > 0) {
+        /* the top of the first mesh's tree, a copy per workgroup (the branch above is uniform over the workgroup) */
+        for (int i = tid; i < S.topCount * 8; i += kBlock) s_top[i] = S.nodes[i];
+        __syncthreads();
+    }
     /* The work queue is cut into kSegments contiguous pieces with a fetch counter each (on a line of its own,
      * kSegPitch dwords apart).  Workgroups are dealt round-robin over the 8 XCDs, so (linear workgroup id) % 8 names the
      * groups that share an L2: each starts on "its" piece and moves on to the others when that runs dry.  Queues
@@ -237,6 +270,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     /* lane states: trav = walking mesh gi; done = that walk has ended and its epilogue is due;
      * neither = wants a new item; exhausted = the counter has run past the last item */
     bool trav = false, done = false, exhausted = false;
+    bool uncertain = false;     /* a mesh walk of the lane's ray gave an answer that depends on the reference's leaf order */
     int pix = -1, gi = 0;
     Ray r; r.o = f3(0.0f); r.d = f3(0.0f);
     Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0; best.uv.y = 0; best.geom = -1; best.tri = -1;
@@ -245,7 +279,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     int shSlot = 0;             /* shadow mode: queue position of the lane's ray (its colour record is read when the verdict is in) */
     MeshTrav tv;
     travInit(S.geoms[firstMesh], r, tv);
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0; cnt.refWalks = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     unsigned long long diag[6] = { 0, 0, 0, 0, 0, 0 };
     unsigned long long tStart = 0, tDry = 0;
     if (COUNT && MODE == TRACE_CLOSEST) {
@@ -262,8 +296,8 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
             bool fetch = !trav && !exhausted;
             if (done) {
                 const DGeom& g = S.geoms[gi];
-                /* the rare ray whose closest hit depends on the order the reference visits its leaves in */
-                if (!travCertain(S, tv)) { travReference(S, g, tv, ovRef); if (COUNT) cnt.refWalks++; }
+                /* the rare ray whose closest hit depends on the order the reference visits its leaves in: k_refwalk redoes it */
+                if (!travCertain(S, tv)) uncertain = true;
                 F3 nn; F2 uv; int mat = 0, tri = -1;
                 float t = travFinish(S, g, r, tv, false, nn, uv, mat, tri);
                 if (COUNT && tv.best >= 0) cnt.meshHits++;
@@ -283,24 +317,20 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
                     travInit(S.geoms[gi], r, tv);
                     trav = true;
                     fetch = false;
-                } else if (MODE == TRACE_CLOSEST) {
-                    const int triWord = S.packGeom ? (best.tri | (best.geom << 26)) : best.tri;
-                    hitARef(S, st, pix, bounce) = make_float4(best.t, best.uv.x, best.uv.y, __int_as_float(triWord));
-                    if (!S.packGeom && best.t > 0.0f) st.hitTri[pix] = best.geom;
                 } else {
-                    /* settle the path colour, then the image add the shade stage held back */
-                    float4 c = st.col[pix];
-                    if (!blocked) {
-                        float4 v = st.shRec[3 * (size_t)shSlot + 2];
-                        c.x = v.x; c.y = v.y; c.z = v.z;
-                        st.col[pix] = c;
+                    /* the ray is finished.  One whose result hangs on the reference's leaf order goes on k_refwalk's list and is
+                     * settled there (its shadow verdict must not be acted on here; its hit record is simply overwritten) */
+                    const unsigned long long um = __ballot(uncertain);
+                    if (um) {
+                        const int leader = __builtin_ctzll(um);
+                        uint32_t at = 0;
+                        if (lane == leader) at = atomicAdd(refCount + blockIdx.y * kCtrStride, (uint32_t)__builtin_popcountll(um));
+                        at = (uint32_t)__shfl((int)at, leader);
+                        if (uncertain) st.refList[(MODE == TRACE_CLOSEST ? 0 : st.numPixels) + at + (uint32_t)__builtin_popcountll(um & lt)] = MODE == TRACE_CLOSEST ? pix : shSlot;
                     }
-                    if (__float_as_int(c.w) <= 0) {
-                        /* the path's one contribution, see k_shade (nothing for a path that ended below zero) */
-                        const bool counts = __float_as_int(c.w) == 0;
-                        float* im = st.image + 3 * (size_t)pix;
-                        im[0] = counts ? c.x : 0.0f; im[1] = counts ? c.y : 0.0f; im[2] = counts ? c.z : 0.0f;
-                    }
+                    if (MODE == TRACE_CLOSEST) writeMeshHit(S, st, pix, bounce, best);
+                    else if (!uncertain) settleShadow(st, pix, shSlot, blocked);
+                    uncertain = false;
                 }
             }
             if (COUNT) { diag[4]++; diag[5] += __builtin_popcountll(__ballot(fetch)); }
@@ -374,7 +404,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
             diag[leafTurn ? 2 : 3] += __builtin_popcountll(leafLanes);
         }
         if (trav) {
-            bool more = travStep<COUNT>(S, tv, stack, ovRef, ovT, cnt, leafTurn);
+            bool more = travStep<COUNT>(S, tv, stack, ovRef, ovT, cnt, leafTurn, s_top);
             if (!more) { trav = false; done = true; }
         }
     }
@@ -394,6 +424,51 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_MINWAVES) k_trace(SceneView S
     }
 }
 
+/* The rays k_trace could not vouch for (travCertain), once more: every BVH mesh of the ray is walked the way the reference
+ * walks it (travReference), which is the definition of the result.  One thread per list entry; the list is normally empty
+ * and at most a handful of entries long (a hit a rounding error outside a triangle's rim with a second hit right behind it). */
+template <int MODE>
+__global__ void __launch_bounds__(64) k_refwalk(SceneView S, PathState st, int bounce, const uint32_t* refCount, DevCounters* dc)
+{
+    st = st.at(blockIdx.y);
+    const uint32_t n = refCount[blockIdx.y * kCtrStride];
+    int stack[64];
+    for (uint32_t i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+        const int id = st.refList[(MODE == TRACE_CLOSEST ? 0 : st.numPixels) + i];
+        Ray r;
+        int pix = id, shLight = -1;
+        float shDist = 0.0f;
+        if (MODE == TRACE_CLOSEST) {
+            float4 o = loadRayO(S, st.rayO, pix, bounce), d = loadRayD(S, st, pix, bounce);
+            r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+        } else {
+            const float4* rec = st.shRec + 3 * (size_t)id;
+            float4 o = rec[0], d = rec[1];
+            pix = __float_as_int(rec[2].w);
+            r.o = f3(o.x, o.y, o.z); r.d = f3(d.x, d.y, d.z);
+            shDist = o.w;
+            shLight = __float_as_int(d.w);
+        }
+        Hit best; best.t = -1.0f; best.n = f3(0.0f); best.mat = 0; best.uv.x = 0.0f; best.uv.y = 0.0f; best.geom = -1; best.tri = -1;
+        bool blocked = false;
+        for (int gi = nextBvhMesh(S, 0); gi >= 0 && !blocked; gi = nextBvhMesh(S, gi + 1)) {
+            const DGeom& g = S.geoms[gi];
+            MeshTrav tv;
+            travInit(g, r, tv);
+            /* a ray with a non-finite origin or direction hits nothing (travInit) */
+            if (__builtin_fabsf(tv.lo.x) < __builtin_inff()) travReference(S, g, tv, stack);
+            F3 nn; F2 uv; int mat = 0, tri = -1;
+            const float t = travFinish(S, g, r, tv, false, nn, uv, mat, tri);
+            if (MODE == TRACE_CLOSEST) {
+                if (closer(t, gi, best)) { best.t = t; best.geom = gi; best.tri = tv.best; best.uv.x = tv.bary.y; best.uv.y = tv.bary.z; }
+            } else blocked = shLight >= 0 ? blocksLight(t, shDist) : blocksEnv(t);
+        }
+        if (MODE == TRACE_CLOSEST) writeMeshHit(S, st, pix, bounce, best);
+        else settleShadow(st, pix, id, blocked);
+    }
+    if (dc && n && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&dc->refWalks, (unsigned long long)n);
+}
+
 /* fold the inline geoms into the mesh result; final hit record, sort bucket, bucket histogram.
  * SPARSE: the grid is bounded and a workgroup walks the 256-slot pieces vb, vb + gridDim.x, ... of its row — for
  * bounces whose rows are known to be nearly empty, where one workgroup per 256 slots of the full image is mostly
@@ -409,7 +484,7 @@ __global__ void __launch_bounds__(kBlock) k_prims(SceneView S, PathState st, Que
     int vb = (int)blockIdx.x;
     if ((uint32_t)(vb * kBlock) >= n) return;
     const int numBuckets = S.numBuckets;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0; cnt.refWalks = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     do {
         const int slot = vb * kBlock + tid;
         if (sortOn) {
@@ -597,7 +672,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_MINWAVES) k_shade(SceneView S
     /* sorted order: the misses are the last bucket, and its first slot is the scanned histogram entry of that bucket's
      * first workgroup — their hit records (distance -1, nothing else read) are not fetched */
     const uint32_t missStart = sortOn ? (uint32_t)q.blockHist[(size_t)(S.numBuckets - 1) * q.numBlocks] : 0xffffffffu;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0; cnt.refWalks = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.meshHits = 0; cnt.boxes = 0; cnt.maxSp = 0;
     do {
         const int slot = vb * kBlock + tid;
         const bool active = (uint32_t)slot < n;
@@ -905,18 +980,23 @@ void ptl_cull(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch b
 {
     hipLaunchKernelGGL(k_cull, dim3(q.numBlocks, bt.count), dim3(kBlock), 0, s, S, st, q, bounce, workCount);
 }
+/* refCount: length of the list of rays k_refwalk settles behind this launch (zero when launched) */
 void ptl_trace(hipStream_t s, const SceneView& S, PathState st, Queues q, Batch bt, int bounce, bool shadow, bool count,
-               uint32_t* fetchCtr, const uint32_t* workCount, void* dc, int share)
+               uint32_t* fetchCtr, const uint32_t* workCount, uint32_t* refCount, void* dc, int share)
 {
     /* share: launches expected to run side by side with this one (they split the machine's workgroup slots) */
     dim3 grid(persistentGridX(bt.count * (share > 1 ? share : 1)), bt.count);
     DevCounters* d = (DevCounters*)dc;
+    /* the follow-up kernel finds its list empty almost always: a few small workgroups per row */
+    const dim3 rgrid(bt.count >= 64 ? 1 : bt.count >= 8 ? 4 : 16, bt.count);
     if (shadow) {
-        if (count) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
-        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_SHADOW, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, refCount, d);
+        else hipLaunchKernelGGL((k_trace<TRACE_SHADOW, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, refCount, d);
+        hipLaunchKernelGGL((k_refwalk<TRACE_SHADOW>), rgrid, dim3(64), 0, s, S, st, bounce, refCount, count ? d : nullptr);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
-        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, d);
+        if (count) hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, true>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, refCount, d);
+        else hipLaunchKernelGGL((k_trace<TRACE_CLOSEST, false>), grid, dim3(kBlock), 0, s, S, st, q, bounce, fetchCtr, workCount, refCount, d);
+        hipLaunchKernelGGL((k_refwalk<TRACE_CLOSEST>), rgrid, dim3(64), 0, s, S, st, bounce, refCount, count ? d : nullptr);
     }
 }
 /* grid of the SPARSE form of the heavy per-slot kernels: about 4096 workgroups over all rows */

@@ -31,7 +31,20 @@
 namespace ptd {
 
 constexpr int kBlock = 256;          /* threads per workgroup of every 1-D kernel (4 waves) */
-constexpr int kLdsStack = 16;        /* traversal stack entries (ref + entry distance) per ray held in LDS */
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 12
+#endif
+#ifndef PT_LDS_TOP
+#define PT_LDS_TOP 0
+#endif
+#ifndef PT_T2_FORM
+#define PT_T2_FORM 0
+#endif
+constexpr int kLdsStack = PT_LDS_STACK; /* traversal stack entries (ref + entry distance) per ray held in LDS */
+/* The first kTopNodes 4-wide nodes of the node array — the top levels of the first BVH mesh, which the host numbers
+ * breadth first — can be kept in LDS by every traversal workgroup (PT_LDS_TOP = number of nodes, 0: none): every ray
+ * starts there, and a step on an LDS-resident node costs the vector L1 no tag look-ups. */
+constexpr int kTopNodes = PT_LDS_TOP;
 constexpr int kStackDepth = 2 * kLdsStack; /* LDS dwords per lane                                    */
 constexpr int kOverflowStack = 64;   /* further entries per ray in private memory, touched only past kLdsStack */
 constexpr int kEmptyRef = 0x7fffffff;
@@ -85,6 +98,7 @@ struct SceneView {
     float envTotalPower;
     int numBuckets;                 /* numMaterials + 1 */
     int numBvhMeshes;               /* mesh geoms traversed through their BVH (0 when BVH use is off) */
+    int topCount;                   /* leading nodes of the node array that traversal workgroups keep in LDS (<= kTopNodes) */
     /* Primary rays share their origin, throughput (1,1,1) and bounce budget: when cameraOrigin is set the camera
      * kernel does not store them and the stages of bounce 0 take them from here (a third of the bytes a primary
      * path moves).  Off for the stage hooks, whose rays come from the caller. */
@@ -151,13 +165,15 @@ struct PathState {
     float4* shRec;
     int* traceQueue;                /* pixels whose ray may hit a BVH mesh, in arrival order (filled by the stage that
                                        creates the ray: camera, shade) */
+    int* refList;                   /* rays whose mesh result depends on the reference's own leaf order and is settled by k_refwalk:
+                                       pixels of closest-hit rays in [0, numPixels), shadow-queue positions in [numPixels, 2 numPixels) */
     size_t numPixels;
     __host__ PT_DEV PathState at(int k) const
     {
         PathState r = *this;
         const size_t off = (size_t)k * numPixels;
         r.rayO += off; r.rayD += off; r.col += off; r.hitA += off; r.hitB += off; r.rayD0 += off; r.hitA0 += off; r.image += 3 * off;
-        r.hitTri += off; r.shRec += 3 * off; r.traceQueue += off;
+        r.hitTri += off; r.shRec += 3 * off; r.traceQueue += off; r.refList += 2 * off;
         return r;
     }
 };
@@ -215,7 +231,7 @@ struct DevCounters {
     uint32_t liveMax[PT_MAX_DEPTH + 2]; /* per bounce, the largest live count over the rows of the last launch group */
 };
 
-struct TravCounters { uint32_t nodes, tris, meshHits, boxes, maxSp, refWalks; };
+struct TravCounters { uint32_t nodes, tris, meshHits, boxes, maxSp; };
 
 constexpr float kPI = 3.1415926535897932384626422832795028841971f;
 constexpr float kTWO_PI = 6.2831853071795864769252867665590057683943f;
@@ -357,7 +373,11 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.closestT = 3.402823466e+38f;
     tv.best = -1;
     tv.bestRank = 0x7fffffff;
+#ifdef PT_EXP_B
+    tv.bary = f3(0.0f);
+#else
     tv.bary = f3(3.402823466e+38f, 0.0f, 0.0f);
+#endif
     tv.sp = 0;
     tv.ref = 0;
     tv.nodeStart = g.nodeStart;
@@ -369,7 +389,9 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
      * and a triangle test against it fails as well. */
     const bool valid = __builtin_fabsf(tv.lo.x) < INF && __builtin_fabsf(tv.lo.y) < INF && __builtin_fabsf(tv.lo.z) < INF &&
                        __builtin_fabsf(tv.ld.x) < INF && __builtin_fabsf(tv.ld.y) < INF && __builtin_fabsf(tv.ld.z) < INF;
-    if (!valid) tv.lo = f3(INF);
+    tv.lo.x = valid ? tv.lo.x : INF;
+    tv.lo.y = valid ? tv.lo.y : INF;
+    tv.lo.z = valid ? tv.lo.z : INF;
     /* The walked boxes are tested with a finite reciprocal: a zero direction component gets 1e25 instead of infinity.
      * With the origin between the two planes of that axis the slab interval then covers every distance that matters
      * (or ends at 0 when the origin lies in a plane, which only the ray's own starting point needs); outside them it
@@ -423,13 +445,20 @@ PT_DEV bool refSlab(F3 bmin, F3 bmax, F3 lo, F3 invDir, float& tMin, float& tMax
  * that order. */
 PT_DEV bool travCertain(const SceneView& S, const MeshTrav& tv)
 {
+#ifdef PT_EXP_A
+    return true;
+#endif
     if (tv.best < 0) return true;
     const float4* b = S.triBox + 2 * ((size_t)tv.triStart + (size_t)tv.best);
     const float4 bmin = b[0], bmax = b[1];
     float tMin, tMax;
     if (!refSlab(f3(bmin.x, bmin.y, bmin.z), f3(bmax.x, bmax.y, bmax.z), tv.lo, 1.0f / tv.ld, tMin, tMax)) return false;
     if (!(tMin > tv.closestT)) return true;
+#if PT_T2_FORM == 2
+    return false;
+#else
     return !(tMin > slackFar(tv.closestT)) && !(tv.bary.x < tMin);
+#endif
 }
 
 /* meshIntersectionTestBVH's own loop (src/intersections.cu:331-386) over the host BVH as built: explicit stack of 64
@@ -474,7 +503,7 @@ PT_DEV void travReference(const SceneView& S, const DGeom& g, MeshTrav& tv, int*
 /* One step: visit tv.ref (a 4-wide node or a leaf), then pop the next entry that can still hold a
  * closer-or-equal hit.  Returns false when the stack has run dry. */
 template <bool COUNT>
-PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt, bool leafTurn = true)
+PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, float* ovT, TravCounters& cnt, bool leafTurn = true, const float4* top = nullptr)
 {
     const float INF = __builtin_inff();
     const int ref = tv.ref;
@@ -493,16 +522,29 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
              * distances: the values the compare-and-select forms of the reference's vector library give (up to the
              * sign of a zero, which no comparison below sees), at two thirds of the instructions.
              * Empty slots fail: their boxes sit at +inf. */
-            const char* base = (const char*)S.nodes;
-            const uint32_t off = ((uint32_t)tv.nodeStart + (uint32_t)ref) * 128u;
+            const uint32_t nodeIdx = (uint32_t)tv.nodeStart + (uint32_t)ref;
+            const uint32_t off = nodeIdx * 128u;
             const uint32_t exitOff = off + 48u;
-            const float4 nX = *(const float4*)(base + (off + tv.selX));
-            const float4 nY = *(const float4*)(base + (off + tv.selY) + 16);
-            const float4 nZ = *(const float4*)(base + (off + tv.selZ) + 32);
-            const float4 fX = *(const float4*)(base + (exitOff - tv.selX));
-            const float4 fY = *(const float4*)(base + (exitOff - tv.selY) + 16);
-            const float4 fZ = *(const float4*)(base + (exitOff - tv.selZ) + 32);
-            const float4 rf = *(const float4*)(base + off + 96);
+            float4 nX, nY, nZ, fX, fY, fZ, rf;
+            if (kTopNodes > 0 && nodeIdx < (uint32_t)S.topCount) {
+                const char* lb = (const char*)top;
+                nX = *(const float4*)(lb + (off + tv.selX));
+                nY = *(const float4*)(lb + (off + tv.selY) + 16);
+                nZ = *(const float4*)(lb + (off + tv.selZ) + 32);
+                fX = *(const float4*)(lb + (exitOff - tv.selX));
+                fY = *(const float4*)(lb + (exitOff - tv.selY) + 16);
+                fZ = *(const float4*)(lb + (exitOff - tv.selZ) + 32);
+                rf = *(const float4*)(lb + off + 96);
+            } else {
+                const char* base = (const char*)S.nodes;
+                nX = *(const float4*)(base + (off + tv.selX));
+                nY = *(const float4*)(base + (off + tv.selY) + 16);
+                nZ = *(const float4*)(base + (off + tv.selZ) + 32);
+                fX = *(const float4*)(base + (exitOff - tv.selX));
+                fY = *(const float4*)(base + (exitOff - tv.selY) + 16);
+                fZ = *(const float4*)(base + (exitOff - tv.selZ) + 32);
+                rf = *(const float4*)(base + off + 96);
+            }
             if (COUNT) {
                 cnt.nodes++;
                 cnt.boxes += (__float_as_int(rf.x) != kEmptyRef) + (__float_as_int(rf.y) != kEmptyRef) +
@@ -571,6 +613,7 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
             F3 bary;
             float tt = hitTriangleRec(ra, rb, rc, tv.lo, tv.ld, bary);
             if (COUNT) cnt.tris++;
+#if PT_T2_FORM == 0
             if (tt > 0.0f) {
                 if (!(tt > tv.closestT)) {
                     const int rank = __float_as_int(rc.z);
@@ -580,6 +623,22 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
                     if (closer || rank < tv.bestRank) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
                 } else if (tt < tv.bary.x) tv.bary.x = tt;
             }
+#elif PT_T2_FORM == 1
+            {
+                const bool hit = tt > 0.0f;
+                const bool closer = hit && tt < tv.closestT;
+                /* the runner-up: the hit this one displaces, this one when it ties or loses */
+                const float cand = closer ? tv.closestT : tt;
+                tv.bary.x = (hit && cand < tv.bary.x) ? cand : tv.bary.x;
+                const int rank = __float_as_int(rc.z);
+                if (closer || (hit && tt == tv.closestT && rank < tv.bestRank)) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
+            }
+#else
+            if (tt > 0.0f && !(tt > tv.closestT)) {
+                const int rank = __float_as_int(rc.z);
+                if (tt < tv.closestT || rank < tv.bestRank) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
+            }
+#endif
             ra = na; rb = nb; rc = nc;
         }
     }

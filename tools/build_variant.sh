@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../cuda-path-tracer_amd/csrc"
 NAME=$1; shift
 OUT=../../variants
 mkdir -p $OUT
-FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c pt_kernels.hip -o $OUT/pt_kernels_$NAME.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmi_pathtrace_$NAME.so host/error.o host/scene_host.o host/gltf_load.o host/image_io.o host/bvh_build.o host/pathtrace_shim.o $OUT/pt_kernels_$NAME.o pt_denoise.o pt_api.o
 rm $OUT/pt_kernels_$NAME.o
