@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo only to rehearse several ranks on a box with fewer GPUs")
     ap.add_argument("--no-sort", action="store_true", help="MATERIAL_SORTING 0")
+    ap.add_argument("--no-collective-at-one", action="store_true", help="one rank: do not set up the process group / run the all-reduce")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: whole iterations until this much time has passed")
     args = ap.parse_args()
 
@@ -163,12 +164,25 @@ def main():
     if args.backend == "gloo":
         local_rank %= max(torch.cuda.device_count(), 1)       # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
+    collective = None           # what reduces the per-rank sums: "rccl" / "gloo", or why there is none
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            collective = "rccl"
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            collective = "gloo"
+    elif args.backend == "nccl" and not args.no_collective_at_one:
+        # one rank: the process group and the all-reduce of the running sum run all the same (a sum over one rank), so that
+        # the path the multi-GPU runs take — RCCL on a tensor the tracer is bound to — has executed on this machine too
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            collective = "rccl"
+        except Exception as e:      # no usable network interface for the bootstrap, say: the single-GPU number does not depend on it
+            collective = "unavailable at one rank: %s" % str(e)[:160]
 
     scene_name, res, depth, desc = WORKLOADS[args.workload]
     sc = make_workload_scene(scenes, pt, scene_name, res, depth, rank)
@@ -241,8 +255,8 @@ def main():
     t0 = time.perf_counter()
     tr.trace_range(*steps_range(args.warmup, args.warmup + args.steps))
     tr.sync()
-    if world > 1:
-        dist.all_reduce(image)                      # RCCL sum of the W*H*3 accumulation buffers
+    if collective in ("rccl", "gloo"):
+        dist.all_reduce(image)                      # RCCL sum of the W*H*3 accumulation buffers (at one rank: over itself)
     barrier()
     t1 = time.perf_counter()
     total_stats = tr.stats()
@@ -479,6 +493,7 @@ def main():
                           "iterations_per_launch_group": B,
                           "ms_per_spp": round(elapsed / max(spp_rank * world, 1) * 1e3, 5),
                           "material_sort": not args.no_sort, "sample_split": "iteration index interleaved over ranks, one RCCL all-reduce of the W*H*3 sum",
+                          "collective": collective,
                           "path_bounces_per_spp": round(pb_spp, 1),
                           "live_paths_per_bounce_last_iteration": live,
                           "secondary_fraction_of_path_bounces": round(1.0 - npix / max(pb_spp, 1.0), 4),
@@ -489,6 +504,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
     return out
 

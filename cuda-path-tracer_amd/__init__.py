@@ -121,6 +121,8 @@ def _load():
         "pt_trace_range": (ip, [vp, ip, ip, ip]),
         "pt_trace_lookahead": (ip, [vp, ip, ip, ip]),
         "pt_bind_host_image": (ip, [vp, vp]),
+        "pt_reduce_sum": (ip, [C.POINTER(vp), ip, ip]),
+        "pt_device_count": (ip, []),
         "pt_host_image_wait": (ip, [vp]),
         "pt_display": (ip, [vp, ip, vp]),
         "pt_download": (ip, [vp, vp]),
@@ -150,6 +152,7 @@ def _load():
         "pt_scene_desc": (C.POINTER(PtSceneDesc), [vp]),
         "pt_scene_set_resolution": (ip, [vp, ip, ip]),
         "pt_scene_set_depth": (ip, [vp, ip]),
+        "pt_scene_set_iterations": (ip, [vp, ip]),
         "pt_scene_add_mesh": (ip, [vp, vp, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
         "pt_scene_import_gltf": (ip, [vp, C.c_char_p, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp)]),
         "pt_scene_log": (C.c_char_p, [vp]),
@@ -512,6 +515,12 @@ class Tracer:
             self.close()
         except Exception:
             pass
+
+
+def reduce_sum(tracers, root=0):
+    """pt_reduce_sum: fold the running sums of several Tracers (sample split in one process) into tracers[root]."""
+    arr = (C.c_void_p * len(tracers))(*[t._h.value for t in tracers])
+    _check(lib.pt_reduce_sum(arr, len(tracers), int(root)), "pt_reduce_sum")
 
 
 def math_eval(fn, a, b=None, device=0):

@@ -470,6 +470,14 @@ int pt_scene_set_depth(PtScene* s, int depth)
     return PT_OK;
 }
 
+int pt_scene_set_iterations(PtScene* s, int iterations)
+{
+    if (!s || iterations < 1) { pt_set_error("pt_scene_set_iterations: iterations must be positive"); return PT_EINVAL; }
+    s->iterations = iterations;
+    s->refresh();
+    return PT_OK;
+}
+
 int pt_scene_add_material(PtScene* s, const PtMaterial* m)
 {
     if (!s || !m) { pt_set_error("pt_scene_add_material: null argument"); return PT_EINVAL; }

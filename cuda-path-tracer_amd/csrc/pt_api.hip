@@ -54,6 +54,7 @@ void ptl_compact(hipStream_t s, Queues q, Batch bt, int bounce, int sortOn);
 void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, float* image, void* dc,
                 const uint32_t* shadowCounts, const uint32_t* closestCounts, int rowStride);
 void ptl_accumulate(hipStream_t s, PathState st, int rows, float* image);
+void ptl_add_image(hipStream_t s, float* dst, const float* src, size_t n);
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba);
 void ptl_gbuffer(hipStream_t s, PathState st, const PtMaterial* materials, int n, float* normals, float* albedo);
 void ptl_average(hipStream_t s, const float* sum, float samples, size_t n3, float* out);
@@ -1678,6 +1679,44 @@ int pt_download(PtContext* c, float* host_rgb)
     return PT_OK;
 }
 
+/* Sample split inside one process: contexts (one per GPU, or several on one GPU) that rendered disjoint iterations of the
+ * same scene; their running sums are folded into contexts[root]'s, in index order.  A sum on another device crosses as
+ * one peer copy (device to device over xGMI where the devices can reach each other, through the host otherwise) into a
+ * buffer on the root's device; the addition runs there.  The other contexts' sums are left as they are. */
+int pt_reduce_sum(PtContext** contexts, int count, int root)
+{
+    if (!contexts || count < 1 || root < 0 || root >= count || !contexts[root]) { pt_set_error("pt_reduce_sum: bad argument"); return PT_EINVAL; }
+    PtContext* r = contexts[root];
+    const size_t n3 = (size_t)r->numPixels * 3;
+    for (int i = 0; i < count; ++i) {
+        if (!contexts[i]) { pt_set_error("pt_reduce_sum: context %d is null", i); return PT_EINVAL; }
+        if (contexts[i]->numPixels != r->numPixels) { pt_set_error("pt_reduce_sum: context %d renders %d pixels, the root %d", i, contexts[i]->numPixels, r->numPixels); return PT_EINVAL; }
+        for (int j = 0; j < i; ++j) if (contexts[j] == contexts[i]) { pt_set_error("pt_reduce_sum: context %d is listed twice", i); return PT_EINVAL; }
+    }
+    /* every contribution is complete before it is read */
+    for (int i = 0; i < count; ++i) { int rc = pt_sync(contexts[i]); if (rc != PT_OK) return rc; }
+    HIP_TRY(hipSetDevice(r->device));
+    float* staging = nullptr;           /* one image on the root's device, for sums that live elsewhere */
+    int rc = PT_OK;
+    for (int i = 0; i < count && rc == PT_OK; ++i) {
+        if (i == root) continue;
+        PtContext* c = contexts[i];
+        const float* src = c->imageSum;
+        if (c->device != r->device) {
+            if (!staging && hipMalloc((void**)&staging, n3 * sizeof(float)) != hipSuccess) { pt_set_error("pt_reduce_sum: out of device memory"); rc = PT_ENOMEM; break; }
+            hipError_t e = hipMemcpyPeerAsync(staging, r->device, c->imageSum, c->device, n3 * sizeof(float), r->stream);
+            if (e != hipSuccess) { pt_set_error("pt_reduce_sum: copy from device %d to device %d failed: %s", c->device, r->device, hipGetErrorString(e)); rc = PT_EHIP; break; }
+            src = staging;
+        }
+        ptl_add_image(r->stream, r->imageSum, src, n3);
+        if (hipGetLastError() != hipSuccess) { pt_set_error("pt_reduce_sum: launch failed"); rc = PT_EHIP; }
+    }
+    r->sumTouchedOnMain = true;
+    if (hipStreamSynchronize(r->stream) != hipSuccess && rc == PT_OK) { pt_set_error("pt_reduce_sum: %s", hipGetErrorString(hipGetLastError())); rc = PT_EHIP; }
+    if (staging) (void)hipFree(staging);
+    return rc;
+}
+
 int pt_bind_image(PtContext* c, float* dev_rgb)
 {
     if (!c) { pt_set_error("pt_bind_image: null context"); return PT_EINVAL; }
@@ -1798,6 +1837,13 @@ int pt_reset_stats(PtContext* c)
 void* pt_stream(PtContext* c) { return c ? (void*)c->stream : nullptr; }
 
 unsigned long long pt_resource_calls(void) { return g_resourceCalls.load(); }
+
+int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 /* the fixed-ray-set hook over staging buffers the caller of this helper owns: rays go through the production
  * intersect stage in chunks of at most `chunk` (<= one image's worth of paths) */

@@ -877,6 +877,13 @@ __global__ void __launch_bounds__(kBlock) k_accumulate4(float4* image, const flo
     image[i] = acc;
 }
 
+/* dst += src over n floats (the fold of another context's running sum, pt_reduce_sum) */
+__global__ void __launch_bounds__(kBlock) k_add_image(float* dst, const float* src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 /* sendImageToPBO (src/pathtrace.cu:145-166): (int)(sum / iter * 255.0) with a double 255.0 */
 __global__ void __launch_bounds__(kBlock) k_display(const float* image, int n, int iter, uint8_t* rgba)
 {
@@ -1054,6 +1061,10 @@ void ptl_finish(hipStream_t s, PathState st, Queues q, Batch bt, int depth, floa
         hipLaunchKernelGGL(k_accumulate4, dim3(gridFor((long long)(n3 / 4))), dim3(kBlock), 0, s, (float4*)image, (float4*)st.image, n3 / 4, bt.count);
     else
         hipLaunchKernelGGL(k_accumulate, dim3(gridFor((long long)n3)), dim3(kBlock), 0, s, image, st.image, n3, bt.count);
+}
+void ptl_add_image(hipStream_t s, float* dst, const float* src, size_t n)
+{
+    hipLaunchKernelGGL(k_add_image, dim3(gridFor((long long)n)), dim3(kBlock), 0, s, dst, src, n);
 }
 void ptl_display(hipStream_t s, const float* image, int n, int iter, uint8_t* rgba)
 {

@@ -37,9 +37,6 @@ constexpr int kBlock = 256;          /* threads per workgroup of every 1-D kerne
 #ifndef PT_LDS_TOP
 #define PT_LDS_TOP 0
 #endif
-#ifndef PT_T2_FORM
-#define PT_T2_FORM 0
-#endif
 constexpr int kLdsStack = PT_LDS_STACK; /* traversal stack entries (ref + entry distance) per ray held in LDS */
 /* The first kTopNodes 4-wide nodes of the node array — the top levels of the first BVH mesh, which the host numbers
  * breadth first — can be kept in LDS by every traversal workgroup (PT_LDS_TOP = number of nodes, 0: none): every ray
@@ -373,11 +370,7 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.closestT = 3.402823466e+38f;
     tv.best = -1;
     tv.bestRank = 0x7fffffff;
-#ifdef PT_EXP_B
-    tv.bary = f3(0.0f);
-#else
     tv.bary = f3(3.402823466e+38f, 0.0f, 0.0f);
-#endif
     tv.sp = 0;
     tv.ref = 0;
     tv.nodeStart = g.nodeStart;
@@ -445,20 +438,13 @@ PT_DEV bool refSlab(F3 bmin, F3 bmax, F3 lo, F3 invDir, float& tMin, float& tMax
  * that order. */
 PT_DEV bool travCertain(const SceneView& S, const MeshTrav& tv)
 {
-#ifdef PT_EXP_A
-    return true;
-#endif
     if (tv.best < 0) return true;
     const float4* b = S.triBox + 2 * ((size_t)tv.triStart + (size_t)tv.best);
     const float4 bmin = b[0], bmax = b[1];
     float tMin, tMax;
     if (!refSlab(f3(bmin.x, bmin.y, bmin.z), f3(bmax.x, bmax.y, bmax.z), tv.lo, 1.0f / tv.ld, tMin, tMax)) return false;
     if (!(tMin > tv.closestT)) return true;
-#if PT_T2_FORM == 2
-    return false;
-#else
     return !(tMin > slackFar(tv.closestT)) && !(tv.bary.x < tMin);
-#endif
 }
 
 /* meshIntersectionTestBVH's own loop (src/intersections.cu:331-386) over the host BVH as built: explicit stack of 64
@@ -603,44 +589,34 @@ PT_DEV bool travStep(const SceneView& S, MeshTrav& tv, int* stack, int* ovRef, f
         if (!leafTurn) return true;     /* hold the leaf until enough lanes of the wave have one */
         const unsigned x = ~(unsigned)ref;
         const int first = (int)(x >> 5), count = (int)(x & 31u) + 1;
+        const float4* tp = S.triHot + 3 * ((size_t)tv.triStart + (size_t)first);
+        /* one triangle against the ray: a new closest hit, a tie that the reference would have met first, or a candidate
+         * for the runner-up distance (see travCertain) */
+#define PT_TEST_TRIANGLE(ra, rb, rc, index)                                                                     \
+        {                                                                                                        \
+            F3 bary;                                                                                             \
+            const float tt = hitTriangleRec(ra, rb, rc, tv.lo, tv.ld, bary);                                     \
+            if (COUNT) cnt.tris++;                                                                               \
+            if (tt > 0.0f) {                                                                                     \
+                if (!(tt > tv.closestT)) {                                                                       \
+                    const int rank = __float_as_int(rc.z);                                                       \
+                    const bool closer = tt < tv.closestT;                                                        \
+                    /* the runner-up: the hit this one displaces, or this one when it only ties */              \
+                    tv.bary.x = closer ? tv.closestT : tt;                                                       \
+                    if (closer || rank < tv.bestRank) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = (index); tv.bestRank = rank; } \
+                } else if (tt < tv.bary.x) tv.bary.x = tt;                                                       \
+            }                                                                                                    \
+        }
         /* the next triangle's record is requested before the current one is tested: one memory round trip
          * per leaf instead of one per triangle */
-        const float4* tp = S.triHot + 3 * ((size_t)tv.triStart + (size_t)first);
         float4 ra = tp[0], rb = tp[1], rc = tp[2];
         for (int i = 0; i < count; ++i) {
             float4 na = ra, nb = rb, nc = rc;
             if (i + 1 < count) { na = tp[3 * (i + 1)]; nb = tp[3 * (i + 1) + 1]; nc = tp[3 * (i + 1) + 2]; }
-            F3 bary;
-            float tt = hitTriangleRec(ra, rb, rc, tv.lo, tv.ld, bary);
-            if (COUNT) cnt.tris++;
-#if PT_T2_FORM == 0
-            if (tt > 0.0f) {
-                if (!(tt > tv.closestT)) {
-                    const int rank = __float_as_int(rc.z);
-                    const bool closer = tt < tv.closestT;
-                    /* the runner-up: the hit this one displaces, or this one when it only ties */
-                    tv.bary.x = closer ? tv.closestT : tt;
-                    if (closer || rank < tv.bestRank) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
-                } else if (tt < tv.bary.x) tv.bary.x = tt;
-            }
-#elif PT_T2_FORM == 1
-            {
-                const bool hit = tt > 0.0f;
-                const bool closer = hit && tt < tv.closestT;
-                /* the runner-up: the hit this one displaces, this one when it ties or loses */
-                const float cand = closer ? tv.closestT : tt;
-                tv.bary.x = (hit && cand < tv.bary.x) ? cand : tv.bary.x;
-                const int rank = __float_as_int(rc.z);
-                if (closer || (hit && tt == tv.closestT && rank < tv.bestRank)) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
-            }
-#else
-            if (tt > 0.0f && !(tt > tv.closestT)) {
-                const int rank = __float_as_int(rc.z);
-                if (tt < tv.closestT || rank < tv.bestRank) { tv.closestT = tt; tv.bary.y = bary.y; tv.bary.z = bary.z; tv.best = first + i; tv.bestRank = rank; }
-            }
-#endif
+            PT_TEST_TRIANGLE(ra, rb, rc, first + i)
             ra = na; rb = nb; rc = nc;
         }
+#undef PT_TEST_TRIANGLE
     }
     /* pop the next entry that can still hold a closer (or equal) hit */
     int sp = tv.sp;

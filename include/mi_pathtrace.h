@@ -293,6 +293,16 @@ int pt_display(PtContext* ctx, int iter, uint8_t* dev_rgba);
  * copies the W*H*3 float running sum to host memory (synchronises). */
 int pt_download(PtContext* ctx, float* host_rgb);
 
+/* Sample split inside one process (no counterpart in the reference, which drives one device, src/main.cpp:202): `count`
+ * contexts — one per GPU, or several on one — have rendered disjoint iterations of the same scene, e.g. context r of R
+ * the iterations 1+r, 1+r+R, ... (pt_trace_range with stride R).  Adds the running sums of the others to
+ * contexts[root]'s, in index order, and waits for the result; a sum on another device crosses as one device-to-device
+ * copy.  The union of the iterations is what one context would have rendered, so the result equals the one-context
+ * image up to the order of the fp32 additions.  All contexts must have the same resolution. */
+int pt_reduce_sum(PtContext** contexts, int count, int root);
+/* devices a context can be created on (0 when there is none or the runtime is not usable) */
+int pt_device_count(void);
+
 /* The running sum lives in caller-provided DEVICE memory (W*H*3 floats), e.g.
  * a torch tensor that a collective reduces afterwards.  NULL = library-owned. */
 int pt_bind_image(PtContext* ctx, float* dev_rgb);
@@ -395,6 +405,7 @@ const PtSceneDesc* pt_scene_desc(const PtScene* s);
 /* Override RES / DEPTH (all shipped scenes are 1200x1200). */
 int pt_scene_set_resolution(PtScene* s, int width, int height);
 int pt_scene_set_depth(PtScene* s, int depth);
+int pt_scene_set_iterations(PtScene* s, int iterations);     /* the ITERATIONS entry of the camera block (src/scene.cpp:868-905) */
 /* Append a triangle mesh object (triangles already carry the object's TRS
  * baked in, as loadGLTFModel does, src/scene.cpp:265,423-425) together with
  * its materials and textures; TRS is kept as the geom transform as well

@@ -550,6 +550,54 @@ def test_sample_split_equals_single_render(pt, scenes, orc, gpu_ok):
     assert single.stats().pathBounces > 0
 
 
+def test_reduce_sum_of_split_contexts(pt, scenes, gpu_ok, tmp_path):
+    """Sample split inside one process (pt_reduce_sum, pt_headless --gpus): R contexts — here on the one GPU of the
+    box — render iterations 1+r, 1+r+R, ... and their running sums are folded into the first.  The union is the
+    one-context render: equal up to the order of the fp32 additions, and bit for bit equal to adding the parts on the
+    host in the same order.  The other contexts' sums are left alone; bad arguments are refused."""
+    import subprocess
+    sc = scenes.make_scene("dragon", res=(96, 64), depth=8, grid=(48, 49), env_size=(64, 32), tex_size=16)
+    n = 12
+    single = pt.Tracer(sc)
+    single.set_option(pt.PT_OPT_BATCH, 4)
+    single.trace_range(1, n + 1)
+    whole = single.image()
+    for R in (2, 3):
+        parts = [pt.Tracer(sc) for _ in range(R)]
+        for r, t in enumerate(parts):
+            t.set_option(pt.PT_OPT_BATCH, 3)
+            t.trace_range(1 + r, n + 1, R)
+        before = [t.image().copy() for t in parts]
+        pt.reduce_sum(parts, root=0)
+        got = parts[0].image()
+        want = before[0].copy()
+        for b in before[1:]:
+            want += b
+        assert _same_bits(got, want)
+        assert np.allclose(got, whole, rtol=1e-5, atol=1e-6)
+        for t, b in zip(parts[1:], before[1:]):
+            assert _same_bits(t.image(), b)
+        assert sum(t.stats().pathBounces for t in parts) == single.stats().pathBounces
+    with pytest.raises(pt.PtError):
+        pt.reduce_sum([parts[0], parts[0]])
+    other = pt.Tracer(scenes.make_scene("cornell", res=(32, 32)))
+    with pytest.raises(pt.PtError, match="pixels"):
+        pt.reduce_sum([parts[0], other])
+    assert pt.lib.pt_device_count() >= 1
+    # the same split through the headless program: two host threads, two contexts, one sum
+    exe = os.path.join(os.path.dirname(pt.LIB_PATH), "pt_headless")
+    path = scenes.write_scene_json("cornell", str(tmp_path))
+    outs = []
+    for extra in (["--batch"], ["--gpus", "2"], ["--gpus", "4"]):
+        out = str(tmp_path / ("split%d.pfm" % len(outs)))
+        subprocess.check_call([exe, path, "-n", "8", "-r", "64", "48", "-d", "6", "-o", out] + extra, timeout=180)
+        with open(out, "rb") as f:
+            f.readline(); f.readline(); f.readline()
+            outs.append(np.frombuffer(f.read(), dtype="<f4").reshape(48, 64, 3))
+    assert outs[0].sum() > 0
+    assert np.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6) and np.allclose(outs[0], outs[2], rtol=1e-5, atol=1e-6)
+
+
 def test_counters(pt, scenes, orc, gpu_ok):
     """Traversal counters: the same closest hits as the oracle (mesh-hit counts are traversal-independent);
     the ordered 4-wide traversal must test fewer triangles than the reference's unordered binary walk."""
