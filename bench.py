@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: whole iterations until this much time has passed")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_WATCHDOG"):        # diagnosis: every thread's traceback on stderr after this many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel hardware-counter summary of one workload from the passes of tools/profile_r02.sh.
+"""Per-kernel hardware-counter summary of one workload from the passes of tools/profile_r03.sh.
 
     python tools/pmc_workload.py <dir with sq/ sq2/ l2/ fetch/ write/ and *_bench.json> <workload>
 
@@ -64,6 +64,7 @@ def last_sum(per_dispatch, n):
 
 def main():
     base, workload = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     bench = json.loads(open(os.path.join(base, "sq_bench.json")).read().strip().splitlines()[-1])
     rl = bench["roofline"]
     depth, steps = bench["config"]["depth"], bench["steps"]
@@ -73,9 +74,9 @@ def main():
     rays = {}
     if "rays_per_launch" in rl:         # scenes without a BVH mesh have no traversal launches
         rays = {"k_trace(closest)": rl["rays_per_launch"] * rl["launches"], "k_trace(shadow)": bench["config"]["shadow_rays_per_spp"] * spp}
-    passes = {p: load(os.path.join(base, p)) for p in ("sq", "sq2", "l2", "fetch", "write")}
+    passes = {p: load(os.path.join(base, p)) for p in ("sq", "sq2", "l2", "fetch", "write", "ea")}
     res = {"_workload": workload, "_bench_line_of_the_sq_pass": {k: bench[k] for k in ("value", "ms_per_step")},
-           "_method": "rocprofv3 --pmc, one pass per counter group (tools/profile_r02.sh), sums over the last %d dispatches of each kernel "
+           "_method": "rocprofv3 --pmc, one pass per counter group (tools/profile_r03.sh), sums over the last %d dispatches of each kernel "
                       "(the single-stream pass of bench.py --steps %d); see tools/pmc_workload.py for the arithmetic" % (n, steps)}
     lines = []
     for _pat, k in NAMES:
@@ -84,6 +85,7 @@ def main():
         nk = n if "trace" in k or k in ("k_shade", "k_prims") else steps
         sq, sq2, l2 = last_sum(passes["sq"][k], nk), last_sum(passes["sq2"].get(k, {}), nk), last_sum(passes["l2"].get(k, {}), nk)
         fe, wr = last_sum(passes["fetch"].get(k, {}), nk), last_sum(passes["write"].get(k, {}), nk)
+        ea = last_sum(passes["ea"].get(k, {}), nk)
         e = {"launches_summed": int(sq["_launches"]), "ms_total_under_counters": round(sq["_ns"] / 1e6, 3)}
         act, wavecyc = sq.get("SQ_ACTIVE_INST_VALU", 0.0), sq.get("SQ_WAVE_CYCLES", 0.0)
         lane = sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / (act * 64.0) if act else None
@@ -120,6 +122,19 @@ def main():
         e["hbm_bytes"] = round(hbm)
         e["hbm_read_bytes(2xFETCH_SIZE)"] = round(2.0 * fe.get("FETCH_SIZE", 0.0) * 1024.0)
         e["hbm_write_bytes"] = round(wr.get("WRITE_SIZE", 0.0) * 1024.0)
+        if ea.get("TCC_EA0_RDREQ_DRAM_32B"):
+            # the L2's own tally of what it asked the memory side for, in 32-byte units: no assumption about request sizes
+            rd32, wr32 = ea["TCC_EA0_RDREQ_DRAM_32B"] * 32.0, ea.get("TCC_EA0_WRREQ_WRITE_DRAM_32B", 0.0) * 32.0
+            e["dram_read_bytes(32B units)"] = round(rd32)
+            e["dram_write_bytes(32B units)"] = round(wr32)
+            e["read_requests_128B"] = ea.get("TCC_EA0_RDREQ_128B")
+            e["read_requests_64B"] = ea.get("TCC_EA0_RDREQ_64B")
+            e["fetch_size_factor"] = round(rd32 / (fe.get("FETCH_SIZE", 0.0) * 1024.0), 3) if fe.get("FETCH_SIZE") else None
+            e["dram_bytes"] = round(rd32 + wr32)
+            if k in rays and rays[k] > 0:
+                e["dram_bytes_per_ray"] = round((rd32 + wr32) / rays[k], 2)
+            if k in ("k_shade", "k_prims") and pb_total > 0:
+                e["dram_bytes_per_path_bounce"] = round((rd32 + wr32) / pb_total, 2)
         if k in rays and rays[k] > 0:
             e["hbm_bytes_per_ray"] = round(hbm / rays[k], 2)
         if k in ("k_shade", "k_prims") and pb_total > 0:
@@ -132,13 +147,13 @@ def main():
             if c in sq2:
                 e[c.lower()] = sq2[c]
         res[k] = e
-        lines.append("%-22s launches %3d  %9.2f ms  VALU issue %5.1f%%  lanes %5.1f%%  VALU share of wave time %5.1f%%  waiting %5.1f%%  L1 tag pipe %5.1f%%  L2 hit %5.1f%%  HBM %8.2f GB (%6.1f GB/s)" % (
+        lines.append("%-22s launches %3d  %9.2f ms  VALU issue %5.1f%%  lanes %5.1f%%  VALU share of wave time %5.1f%%  waiting %5.1f%%  L1 tag pipe %5.1f%%  L2 hit %5.1f%%  HBM %8.2f GB (%6.1f GB/s)  DRAM 32-byte tally %8.2f GB (x%.2f of FETCH_SIZE)" % (
             k, e["launches_summed"], e["ms_total_under_counters"], 100 * (e["valu_issue_utilisation"] or 0), 100 * (lane or 0),
             100 * (e["valu_share_of_wave_time"] or 0), 100 * (e["wait_any_share_of_wave_time"] or 0), 100 * (e["l1_tag_busy"] or 0), 100 * (e["l2_hit_rate"] or 0),
-            hbm / 1e9, e["hbm_gbs_under_counters"] or 0))
+            hbm / 1e9, e["hbm_gbs_under_counters"] or 0, (e.get("dram_bytes") or 0) / 1e9, e.get("fetch_size_factor") or 0))
     out = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
     json.dump(res, open(out, "w"), indent=1)
-    txt = os.path.join(ROOT, "profiles", "r02_units_%s.txt" % workload)
+    txt = os.path.join(ROOT, "profiles", "%s_units_%s.txt" % (tag, workload))
     open(txt, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     print("wrote", out, "and", txt)
