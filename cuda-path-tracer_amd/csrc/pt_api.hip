@@ -1248,11 +1248,27 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     for (int t = 0; t < d->textureCount; ++t) {
         const PtTexture& pt = d->textures[t];
         if (!pt.data || pt.width <= 0 || pt.height <= 0 || pt.components < 1 || pt.components > 4) { pt_set_error("pt_create: texture %d is invalid", t); pt_destroy(c); return PT_EINVAL; }
-        uint8_t* dd;
-        /* +4 bytes so the 4-byte RGBA fetch of the last texel stays inside the allocation for 3-component images too */
-        TRY_RC(devAlloc(c, &dd, (size_t)pt.width * pt.height * pt.components + 4));
-        TRY_HIP(hipMemcpy(dd, pt.data, (size_t)pt.width * pt.height * pt.components, hipMemcpyHostToDevice));
-        tex[t].data = dd; tex[t].width = pt.width; tex[t].height = pt.height; tex[t].components = pt.components; tex[t].pad = 0;
+        /* device copy: four bytes per texel (grey replicated, alpha 255 where the image has none) in 8 x 4-texel tiles
+         * of 128 bytes, edges padded to whole tiles; see sampleTexture */
+        const int tilesX = (pt.width + kTexTileW - 1) / kTexTileW, tilesY = (pt.height + kTexTileH - 1) / kTexTileH;
+        std::vector<uint32_t> tiled((size_t)tilesX * tilesY * kTexTileW * kTexTileH, 0u);
+        if (pt.components != 2) {
+            for (int y = 0; y < pt.height; ++y) {
+                const uint8_t* row = pt.data + (size_t)y * pt.width * pt.components;
+                uint32_t* out = tiled.data() + ((size_t)(y / kTexTileH) * tilesX) * 32 + (size_t)(y % kTexTileH) * kTexTileW;
+                for (int x = 0; x < pt.width; ++x) {
+                    const uint8_t* px = row + (size_t)x * pt.components;
+                    uint32_t v;
+                    if (pt.components == 1) v = px[0] * 0x010101u | 0xff000000u;
+                    else if (pt.components == 3) v = px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | 0xff000000u;
+                    else v = px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | (uint32_t)px[3] << 24;
+                    out[(size_t)(x / kTexTileW) * 32 + (x % kTexTileW)] = v;
+                }
+            }
+        }
+        uint32_t* dd;
+        TRY_RC(devUpload(c, &dd, tiled.data(), tiled.size()));
+        tex[t].data = reinterpret_cast<const uint8_t*>(dd); tex[t].width = pt.width; tex[t].height = pt.height; tex[t].components = pt.components; tex[t].tilesPerRow = tilesX;
     }
     DTexture* dTex;
     TRY_RC(devUpload(c, &dTex, tex.data(), tex.size()));
@@ -1274,19 +1290,39 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
 
     /* ---- environment map + CDFs (src/pathtrace.cu:453-476) */
     const bool envOn = d->env.enabled && d->env.data && d->env.width > 0 && d->env.height > 0;
-    float* dEnv = nullptr; float* dMarg = nullptr; float* dCond = nullptr; float totalPower = 0.0f;
+    float* dEnv = nullptr; float* dMarg = nullptr; float* dCond = nullptr; uint16_t* dGuide = nullptr; float totalPower = 0.0f;
     if (envOn) {
         std::vector<float> marg, cond;
         buildEnvCdfs(d->env, marg, cond, totalPower);
         TRY_RC(devUpload(c, &dEnv, d->env.data, (size_t)d->env.width * d->env.height * 3));
         TRY_RC(devUpload(c, &dMarg, marg.data(), marg.size()));
         TRY_RC(devUpload(c, &dCond, cond.data(), cond.size()));
+        /* guide tables of the CDF searches (lowerBoundGuided): the answers for the multiples of 1/64, for the marginal CDF and
+         * for every row of the conditional one; only when no CDF starts below zero, ever decreases or holds a NaN, and indices fit 16 bits */
+        const int W = d->env.width, H = d->env.height;
+        auto monotone = [](const float* f, int n) { if (!(f[0] >= 0.0f)) return false; for (int i = 1; i < n; ++i) if (!(f[i] >= f[i - 1])) return false; return true; };
+        bool guided = W <= 65536 && H <= 65536 && monotone(marg.data(), H);
+        for (int y = 0; y < H && guided; ++y) guided = monotone(cond.data() + (size_t)y * W, W);
+        if (guided) {
+            std::vector<uint16_t> guide((size_t)(H + 1) * kCdfGuide);
+            auto fill = [](const float* f, int n, uint16_t* g) {
+                int at = 0;
+                for (int j = 0; j < kCdfGuide; ++j) {
+                    const float v = (float)j / (float)kCdfGuide;
+                    while (at < n - 1 && f[at] < v) ++at;        /* first entry >= v, or n - 1 */
+                    g[j] = (uint16_t)at;
+                }
+            };
+            fill(marg.data(), H, guide.data());
+            for (int y = 0; y < H; ++y) fill(cond.data() + (size_t)y * W, W, guide.data() + (size_t)(y + 1) * kCdfGuide);
+            TRY_RC(devUpload(c, &dGuide, guide.data(), guide.size()));
+        }
     }
 
     SceneView& V = c->view;
     V.cameraOrigin = 0; V.leanHits = 0; V.traceDepth = c->traceDepth; memcpy(V.camPos, c->cam.position, sizeof(V.camPos));     /* set per call in traceBatch */
     V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.triBox = dBox; V.leafOfOrig = dLeaf; V.hostNodes = dHostNodes; V.hostIndices = dHostIdx;
-    V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond;
+    V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond; V.envGuide = dGuide;
     V.numGeoms = d->geomCount; V.numMaterials = d->materialCount; V.numTextures = d->textureCount; V.numLights = (int)lights.size();
     V.envWidth = envOn ? d->env.width : 0; V.envHeight = envOn ? d->env.height : 0; V.envEnabled = envOn ? 1 : 0; V.useBvh = 1;
     V.envTotalPower = totalPower;

@@ -72,7 +72,7 @@ struct DGeom {
 };
 static_assert(sizeof(DGeom) == 288, "DGeom layout");
 
-struct DTexture { const uint8_t* data; int width, height, components, pad; };
+struct DTexture { const uint8_t* data; int width, height, components, tilesPerRow; };   /* data: 4-byte texels in 8 x 4 tiles, see sampleTexture */
 struct DLight { int geomIdx; float area; float pdf; };
 
 struct SceneView {
@@ -90,6 +90,7 @@ struct SceneView {
     const float* envData;
     const float* envMarginal;
     const float* envConditional;
+    const uint16_t* envGuide;   /* guide tables of the CDF searches (lowerBoundGuided): kCdfGuide entries for the marginal CDF, then as many per row of the conditional one; null: none */
     int numGeoms, numMaterials, numTextures, numLights;
     int envWidth, envHeight, envEnabled, useBvh;
     float envTotalPower;
@@ -817,24 +818,23 @@ PT_DEV F3 sampleHemisphere(F3 normal, Lcg& rng)
     return up * normal + dm::cos(around) * over * p1 + dm::sin(around) * over * p2;
 }
 
-/* hand-written bilinear fetch on interleaved 8-bit texels, repeat wrap, no sRGB decode
- * (src/pathtrace.cu:937-1019) */
-PT_DEV F4 fetchTexel(const DTexture& tex, int x, int y)
+/* hand-written bilinear fetch on 8-bit texels, repeat wrap, no sRGB decode (src/pathtrace.cu:937-1019).
+ * The device copy of a texture holds four bytes per texel whatever the file had (grey replicated, alpha 255 where there
+ * was none: 255 / 255.0f is the 1.0f the reference sets), in tiles of 8 x 4 texels = one 128-byte line each, so that a
+ * 2 x 2 footprint is four 4-byte loads which mostly share a line instead of two lines of a row-major image.  The values
+ * fetched, and all arithmetic on them, are the reference's. */
+constexpr int kTexTileW = 8, kTexTileH = 4;
+PT_DEV int texRowPart(const DTexture& tex, int y) { return (y >> 2) * tex.tilesPerRow * 32 + ((y & 3) << 3); }
+PT_DEV int texColPart(int x) { return ((x >> 3) << 5) + (x & 7); }
+PT_DEV F4 decodeTexel(uint32_t p)
 {
-    int idx = (y * tex.width + x) * tex.components;
-    const uint8_t* d = tex.data;
     F4 r;
-    if (tex.components == 3) { r.x = d[idx] / 255.0f; r.y = d[idx + 1] / 255.0f; r.z = d[idx + 2] / 255.0f; r.w = 1.0f; }
-    else if (tex.components == 4) {
-        uint32_t p = *reinterpret_cast<const uint32_t*>(d + idx);       /* one 4-byte load per RGBA texel */
-        r.x = (p & 255u) / 255.0f; r.y = ((p >> 8) & 255u) / 255.0f; r.z = ((p >> 16) & 255u) / 255.0f; r.w = (p >> 24) / 255.0f;
-    }
-    else if (tex.components == 1) { float v = d[idx] / 255.0f; r.x = v; r.y = v; r.z = v; r.w = 1.0f; }
-    else { r.x = 1.0f; r.y = 0.0f; r.z = 1.0f; r.w = 1.0f; }
+    r.x = (p & 255u) / 255.0f; r.y = ((p >> 8) & 255u) / 255.0f; r.z = ((p >> 16) & 255u) / 255.0f; r.w = (p >> 24) / 255.0f;
     return r;
 }
 PT_DEV F4 sampleTexture(const DTexture& tex, F2 uv)
 {
+    if (tex.components == 2) { F4 m; m.x = 1.0f; m.y = 0.0f; m.z = 1.0f; m.w = 1.0f; return m; }   /* two-channel images: the reference's magenta */
     uv.x = uv.x - __builtin_floorf(uv.x);
     uv.y = uv.y - __builtin_floorf(uv.y);
     float fx = uv.x * (tex.width - 1);
@@ -845,7 +845,10 @@ PT_DEV F4 sampleTexture(const DTexture& tex, F2 uv)
     int y1 = min(y0 + 1, tex.height - 1);
     float wx = fx - x0;
     float wy = fy - y0;
-    F4 p00 = fetchTexel(tex, x0, y0), p10 = fetchTexel(tex, x1, y0), p01 = fetchTexel(tex, x0, y1), p11 = fetchTexel(tex, x1, y1);
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(tex.data);
+    const int r0 = texRowPart(tex, y0), r1 = texRowPart(tex, y1), c0 = texColPart(x0), c1 = texColPart(x1);
+    const uint32_t q00 = d[r0 + c0], q10 = d[r0 + c1], q01 = d[r1 + c0], q11 = d[r1 + c1];
+    F4 p00 = decodeTexel(q00), p10 = decodeTexel(q10), p01 = decodeTexel(q01), p11 = decodeTexel(q11);
     F4 p0 = p00 * (1.0f - wx) + p10 * wx;
     F4 p1 = p01 * (1.0f - wx) + p11 * wx;
     return p0 * (1.0f - wy) + p1 * wy;
@@ -922,6 +925,26 @@ PT_DEV int lowerBound(const float* cdf, int size, float value)
     return left;
 }
 
+/* lowerBound with a guide table.  For a CDF that never decreases (the host checks, and passes no guide otherwise) the
+ * first entry >= value lies between the answers for the multiples of 1/64 on either side of value; guide[j] is the
+ * answer for j/64 (64 entries of 16 bits = one 128-byte line per CDF), and value * 64 and j / 64 are exact in binary
+ * floating point, so the bisection starts on a window of a few dozen entries — one or two lines of the CDF and five or
+ * six dependent loads instead of the eleven, over six lines, that halving a 2 048-entry row takes.  Same index as
+ * lowerBound(cdf, size, value), including size - 1 when no entry qualifies. */
+constexpr int kCdfGuide = 64;
+PT_DEV int lowerBoundGuided(const float* cdf, int size, const uint16_t* guide, float value)
+{
+    if (!guide) return lowerBound(cdf, size, value);
+    int j = (int)(value * (float)kCdfGuide);
+    j = max(0, min(j, kCdfGuide - 1));
+    int left = guide[j], right = j + 1 < kCdfGuide ? (int)guide[j + 1] : size - 1;
+    while (left < right) {
+        int mid = (left + right) / 2;
+        if (cdf[mid] < value) left = mid + 1; else right = mid;
+    }
+    return left;
+}
+
 /* env-map importance sample: row by marginal CDF, column by conditional CDF
  * (src/pathtrace.cu:1412-1472) */
 PT_DEV F3 sampleEnvImportance(const SceneView& S, Lcg& rng, F3& outDir, float& outPdf)
@@ -933,10 +956,9 @@ PT_DEV F3 sampleEnvImportance(const SceneView& S, Lcg& rng, F3& outDir, float& o
     }
     float u = rng.u01();
     float v = rng.u01();
-    int y = lowerBound(S.envMarginal, S.envHeight, v);
+    int y = lowerBoundGuided(S.envMarginal, S.envHeight, S.envGuide, v);
     y = min(y, S.envHeight - 1);
-    const float* rowCDF = S.envConditional + (size_t)y * S.envWidth;
-    int x = lowerBound(rowCDF, S.envWidth, u);
+    int x = lowerBoundGuided(S.envConditional + (size_t)y * S.envWidth, S.envWidth, S.envGuide ? S.envGuide + (size_t)(y + 1) * kCdfGuide : nullptr, u);
     x = min(x, S.envWidth - 1);
     float phi = (x + 0.5f) * 2.0f * kPI / S.envWidth - kPI;
     float theta = (y + 0.5f) * kPI / S.envHeight;
