@@ -87,7 +87,7 @@ struct SceneView {
     const int* hostIndices;     /* travReference, for the rare ray whose result depends on the reference's own visiting order */
     const DTexture* textures;
     const DLight* lights;
-    const float* envData;
+    const float4* envData;      /* one 16-byte texel per pixel of the map (rgb, unused) */
     const float* envMarginal;
     const float* envConditional;
     const uint16_t* envGuide;   /* guide tables of the CDF searches (lowerBoundGuided): kCdfGuide entries for the marginal CDF, then as many per row of the conditional one; null: none */
@@ -835,6 +835,9 @@ PT_DEV F4 decodeTexel(uint32_t p)
 PT_DEV F4 sampleTexture(const DTexture& tex, F2 uv)
 {
     if (tex.components == 2) { F4 m; m.x = 1.0f; m.y = 0.0f; m.z = 1.0f; m.w = 1.0f; return m; }   /* two-channel images: the reference's magenta */
+#ifdef PT_AUDIT_NOTEX           /* byte audit (tools/audit_bytes.sh): every lookup lands on one texel; results are not the reference's */
+    uv.x = 0.25f; uv.y = 0.25f;
+#endif
     uv.x = uv.x - __builtin_floorf(uv.x);
     uv.y = uv.y - __builtin_floorf(uv.y);
     float fx = uv.x * (tex.width - 1);
@@ -856,8 +859,11 @@ PT_DEV F4 sampleTexture(const DTexture& tex, F2 uv)
 
 PT_DEV F3 envTexel(const SceneView& S, int x, int y)
 {
-    const float* p = S.envData + 3 * ((size_t)y * S.envWidth + x);
-    return f3(p[0], p[1], p[2]);
+#ifdef PT_AUDIT_NOENV           /* byte audit: every lookup lands in one corner of the map */
+    x &= 7; y &= 7;
+#endif
+    const float4 p = S.envData[(size_t)y * S.envWidth + x];
+    return f3(p.x, p.y, p.z);
 }
 /* equirect bilinear lookup with clamp, no seam wrap (src/pathtrace.cu:1030-1075) */
 PT_DEV F3 sampleEnv(const SceneView& S, F3 dir)
@@ -935,6 +941,9 @@ constexpr int kCdfGuide = 64;
 PT_DEV int lowerBoundGuided(const float* cdf, int size, const uint16_t* guide, float value)
 {
     if (!guide) return lowerBound(cdf, size, value);
+#ifdef PT_AUDIT_NOCDF           /* byte audit: no CDF is read */
+    return (int)(value * (size - 1));
+#endif
     int j = (int)(value * (float)kCdfGuide);
     j = max(0, min(j, kCdfGuide - 1));
     int left = guide[j], right = j + 1 < kCdfGuide ? (int)guide[j + 1] : size - 1;
