@@ -24,6 +24,7 @@ static PtContext* ctx = nullptr;
 static Scene* hst_scene = nullptr;
 static GuiDataContainer* guiData = nullptr;
 static int lookahead = 0;               /* iterations rendered ahead of the calls (0: one per call) */
+static bool strictHostCopy = true;      /* pathtrace() returns with scene->state.image up to date (PT_HOST_COPY=queued: see pathtrace) */
 
 static void die(const char* what)
 {
@@ -120,6 +121,15 @@ void pathtraceInit(Scene* scene)
     /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): its memory is
      * page-locked where it lies, so the copy runs asynchronously at the bus rate */
     if (pt_bind_host_image(ctx, reinterpret_cast<float*>(scene->state.image.data())) != PT_OK) die("pathtraceInit");
+    const char* copyEnv = getenv("PT_HOST_COPY");
+    strictHostCopy = !(copyEnv && strcmp(copyEnv, "queued") == 0);
+}
+
+/* PT_HOST_COPY=queued: the call that must find scene->state.image complete (saveImage, src/main.cpp:292-318) makes this
+ * one first; declared by the maintainer next to the reference's four functions */
+void pathtraceHostImageWait()
+{
+    if (ctx && pt_host_image_wait(ctx) != PT_OK) die("pathtraceHostImageWait");
 }
 
 void pathtrace(uchar4* pbo, int /* frame */, int iter)
@@ -129,7 +139,9 @@ void pathtrace(uchar4* pbo, int /* frame */, int iter)
     const int last = (int)hst_scene->state.iterations;                      /* the loop saves and exits there (src/main.cpp:831-837) */
     if (pt_trace_lookahead(ctx, iter, lookahead > 0 ? lookahead : 1, iter <= last ? last : 0) != PT_OK) die("pathtrace");
     if (pbo && pt_display(ctx, iter, reinterpret_cast<uint8_t*>(pbo)) != PT_OK) die("pathtrace");      /* pbo: a device pointer, as the GL interop map yields */
-    /* the running sum is back on the host when the call returns, as after the blocking copy at src/pathtrace.cu:2913-2917
-     * (a maintainer who only reads the image in saveImage moves this wait there) */
-    if (pt_host_image_wait(ctx) != PT_OK) die("pathtrace");
+    /* The running sum is back on the host when the call returns, as after the blocking copy at src/pathtrace.cu:2913-2917.
+     * With PT_HOST_COPY=queued the copy of this call is only queued — it runs while the next call is being made, each copy
+     * in call order — and the call that ends the render (the loop saves the image right after it, src/main.cpp:831-837)
+     * waits; any other reader of scene->state.image calls pathtraceHostImageWait() first. */
+    if ((strictHostCopy || iter >= last) && pt_host_image_wait(ctx) != PT_OK) die("pathtrace");
 }

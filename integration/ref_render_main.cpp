@@ -17,6 +17,15 @@
 #include <string>
 
 struct uchar4;
+void pathtraceHostImageWait();      /* integration/pathtrace_mi355x.cpp */
+
+/* FNV-1a over a block of loader output: two runs that print different values were not given the same scene */
+static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
 
 int main(int argc, char** argv)
 {
@@ -57,6 +66,16 @@ int main(int argc, char** argv)
     cameraPosition += cam.lookAt;
     cam.position = cameraPosition;
 
+    {
+        uint64_t hm = fnv(scene->materials.data(), scene->materials.size() * sizeof(Material));
+        uint64_t hg = fnv(scene->geoms.data(), scene->geoms.size() * sizeof(Geom));
+        uint64_t ht = 1469598103934665603ull;
+        for (const MeshData& md : scene->meshes) ht = fnv(md.triangles.data(), md.triangles.size() * sizeof(Triangle), ht);
+        uint64_t he = fnv(scene->environmentMap.data.data(), scene->environmentMap.data.size() * sizeof(glm::vec3));
+        uint64_t hc = fnv(&cam, sizeof(Camera));
+        fprintf(stderr, "ref_render: loader output hashes: materials %016llx, geoms %016llx (these hold a pointer), triangles %016llx, environment %016llx, camera %016llx\n",
+                (unsigned long long)hm, (unsigned long long)hg, (unsigned long long)ht, (unsigned long long)he, (unsigned long long)hc);
+    }
     GuiDataContainer gui;
     InitDataContainer(&gui);
     pathtraceFree();                                    /* src/main.cpp:814 */
@@ -73,15 +92,19 @@ int main(int argc, char** argv)
             t0 = t1;
         }
     }
+    pathtraceHostImageWait();
     const double restMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const char* copyEnv = getenv("PT_HOST_COPY");
+    const bool queued = copyEnv && std::string(copyEnv) == "queued";
     FILE* f = fopen(argv[3], "wb");
     if (!f) { fprintf(stderr, "cannot write %s\n", argv[3]); return 2; }
     int32_t wh[2] = { cam.resolution.x, cam.resolution.y };
     fwrite(wh, 4, 2, f);
     fwrite(scene->state.image.data(), 12, scene->state.image.size(), f);
     fclose(f);
-    fprintf(stderr, "ref_render: %d iterations at %dx%d, traced depth %d, first pathtrace() call %.3f ms, the other %d calls %.4f ms each (host image up to date after every call)\n",
-            iterations, cam.resolution.x, cam.resolution.y, gui.TracedDepth, firstMs, iterations - 1, iterations > 1 ? restMs / (iterations - 1) : 0.0);
+    fprintf(stderr, "ref_render: %d iterations at %dx%d, traced depth %d, first pathtrace() call %.3f ms, the other %d calls %.4f ms each (%s)\n",
+            iterations, cam.resolution.x, cam.resolution.y, gui.TracedDepth, firstMs, iterations - 1, iterations > 1 ? restMs / (iterations - 1) : 0.0,
+            queued ? "host copies queued in call order, the last one waited for" : "host image up to date after every call");
     pathtraceFree();
     return 0;
 }

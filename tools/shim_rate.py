@@ -80,20 +80,37 @@ def main():
     path = os.path.join(out, a.workload + "_shim.json")
     with open(path, "w") as f:
         json.dump(d, f, indent=1)
-    env = dict(os.environ)
-    env.pop("LD_BIND_NOW", None)
-    env["PT_LOOKAHEAD"] = str(a.lookahead)
-    r = subprocess.run([render, path, str(a.calls), os.path.join(out, "sum.bin"), str(a.res[0]), str(a.res[1])],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
-    err = r.stderr.decode(errors="replace")
-    if r.returncode != 0:
-        sys.exit("ref_render failed (%d): %s" % (r.returncode, err[-800:]))
-    line = [l for l in err.splitlines() if l.startswith("ref_render:")][-1]
-    raw = open(os.path.join(out, "sum.bin"), "rb").read()
-    w, h = np.frombuffer(raw[:8], np.int32)
-    img = np.frombuffer(raw[8:], np.float32)
-    print("%s | %d triangles through the reference's loader, look-ahead %d, mean radiance of the sum / calls = %.5f, finite: %s"
-          % (line, len(tris), a.lookahead, float(img.mean()) / a.calls, bool(np.isfinite(img).all())))
+    # The reference's loadGLTFMaterial fills a `Material mat;` that is never zeroed (src/scene.cpp:96): index of refraction,
+    # the specular block and every subsurface field of a glTF material are whatever the stack held, so two processes need
+    # not load the same scene (ref_render prints a hash of what the loader produced).  The two modes are compared bit for
+    # bit where the scene is under control (tests/test_gpu_parity.py::test_lookahead_calls_bit_exact, tools/diag/lookahead_full.py);
+    # here the sums are compared only when the material bytes of the two runs agree.
+    runs = []
+    for mode in ("strict", "queued", "queued"):
+        env = dict(os.environ)
+        env.pop("LD_BIND_NOW", None)
+        env["PT_LOOKAHEAD"] = str(a.lookahead)
+        env["PT_HOST_COPY"] = mode
+        r = subprocess.run([render, path, str(a.calls), os.path.join(out, "sum.bin"), str(a.res[0]), str(a.res[1])],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+        err = r.stderr.decode(errors="replace")
+        if r.returncode != 0:
+            sys.exit("ref_render failed (%d): %s" % (r.returncode, err[-800:]))
+        line = [l for l in err.splitlines() if l.startswith("ref_render:") and "hashes" not in l][-1]
+        hashes = [l for l in err.splitlines() if "hashes" in l][-1]
+        mat_hash = hashes.split("materials ")[1].split(",")[0]
+        raw = open(os.path.join(out, "sum.bin"), "rb").read()
+        img = np.frombuffer(raw[8:], np.float32).copy()
+        runs.append((mode, mat_hash, img))
+        print("%s | %d triangles through the reference's loader, look-ahead %d, material bytes %s, mean radiance of the sum / calls = %.5f, finite: %s"
+              % (line, len(tris), a.lookahead, mat_hash, float(img.mean()) / a.calls, bool(np.isfinite(img).all())), flush=True)
+    for i in range(len(runs)):
+        for j in range(i + 1, len(runs)):
+            if runs[i][1] == runs[j][1]:
+                same = bool((runs[i][2].view(np.uint32) == runs[j][2].view(np.uint32)).all())
+                print("runs %d (%s) and %d (%s) loaded the same material bytes: sums bit-identical: %s" % (i, runs[i][0], j, runs[j][0], same))
+                if not same:
+                    sys.exit("two runs of one scene differ")
 
 
 if __name__ == "__main__":
