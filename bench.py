@@ -417,7 +417,7 @@ def main():
             # every call, as the reference's pathtrace() does (src/pathtrace.cu:2913-2917).  This is the call sequence of
             # integration/pathtrace_mi355x.cpp (the file a maintainer of the reference adds), made through the C ABI.
             import numpy as np
-            ahead = int(os.environ.get("PT_LOOKAHEAD", "64") or 64)
+            ahead = int(os.environ.get("PT_LOOKAHEAD", "128") or 128)
             ahead = max(2, min(ahead, B // 2))
             host = np.zeros((res[1], res[0], 3), np.float32)
             tr.set_option(pt.PT_OPT_LAUNCH_STREAMS, 1)

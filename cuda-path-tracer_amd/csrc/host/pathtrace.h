@@ -44,7 +44,7 @@ void pathtraceSetMaterialSorting(int on);
  * call and pathtraceHostImageWait() waits for the latest one (before saveImage reads the image); 0 no copy */
 void pathtraceSetHostCopy(int mode);
 void pathtraceHostImageWait();
-/* iterations rendered ahead of the calls (default 64, environment PT_LOOKAHEAD; 0 or 1: one iteration per call).  Path
+/* iterations rendered ahead of the calls (default 128, environment PT_LOOKAHEAD; 0 or 1: one iteration per call).  Path
  * state for twice as many iterations is allocated, about 195 bytes per pixel each. */
 void pathtraceSetLookahead(int iterations);
 void pathtraceRange(int firstIteration, int lastIterationInclusive);    /* batched iterations, then one host copy */

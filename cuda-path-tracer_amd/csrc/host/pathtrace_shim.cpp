@@ -16,7 +16,7 @@ int g_hostCopy = 1;
 int g_lookahead = -1;           /* iterations rendered ahead of the calls; -1: PT_LOOKAHEAD or the default */
 int g_ahead = 0;                /* what the context in use was set up for (0: one iteration per call) */
 int g_traceDepth = 0, g_lastIteration = 0;
-constexpr int kDefaultLookahead = 64;
+constexpr int kDefaultLookahead = 128;
 
 void check(int rc, const char* what)
 {

@@ -165,6 +165,10 @@ struct PtContext {
     bool hostRegistered = false;
     float* hostStaging = nullptr;
     hipEvent_t hostCopyDone = nullptr;
+    /* through the staging buffer the image travels in kHostCopyParts pieces with an event each, so that the host's own
+     * copy of a piece runs while the next piece is still on the bus */
+    static constexpr int kHostCopyParts = 4;
+    hipEvent_t hostPartDone[kHostCopyParts] = {};
     bool hostCopyPending = false;
     PtCamera cam{};
     int traceDepth = 8;
@@ -1065,6 +1069,7 @@ int pt_destroy(PtContext* c)
     if (c->hostImage && c->hostRegistered) (void)hipHostUnregister(c->hostImage);
     if (c->hostStaging) (void)hipHostFree(c->hostStaging);
     if (c->serveStream) (void)hipStreamDestroy(c->serveStream);
+    for (hipEvent_t e : c->hostPartDone) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : { c->servedEvent, c->sumReadyEvent, c->hostCopyDone, c->aheadCur.done, c->aheadNext.done })
         if (e) (void)hipEventDestroy(e);
     resolveSpans(c);
@@ -1140,6 +1145,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     TRY_HIP(hipEventCreateWithFlags(&c->servedEvent, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->sumReadyEvent, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->hostCopyDone, hipEventDisableTiming));
+    for (hipEvent_t& e : c->hostPartDone) TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->aheadCur.done, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&c->aheadNext.done, hipEventDisableTiming));
     TRY_HIP(hipHostMalloc((void**)&c->liveHintHost, sizeof(uint32_t) * (PT_MAX_DEPTH + 2), hipHostMallocDefault));
@@ -1608,12 +1614,26 @@ static int serveAfterMain(PtContext* c)
     return PT_OK;
 }
 
+/* byte offset at which piece k of a staged host copy starts (pieces of whole 4 KB pages) */
+static size_t hostPartStart(size_t bytes, int k)
+{
+    const size_t pages = (bytes + 4095) / 4096;
+    return std::min(bytes, pages * (size_t)k / PtContext::kHostCopyParts * 4096);
+}
+
 /* copy of the running sum into the bound host image, behind whatever the stream holds */
 static int queueHostCopy(PtContext* c, hipStream_t st)
 {
     if (!c->hostImage) return PT_OK;
     const size_t bytes = (size_t)c->numPixels * 3 * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(c->hostRegistered ? c->hostImage : c->hostStaging, c->imageSum, bytes, hipMemcpyDeviceToHost, st));
+    if (c->hostRegistered) HIP_TRY(hipMemcpyAsync(c->hostImage, c->imageSum, bytes, hipMemcpyDeviceToHost, st));
+    else {
+        for (int k = 0; k < PtContext::kHostCopyParts; ++k) {
+            const size_t a = hostPartStart(bytes, k), b = hostPartStart(bytes, k + 1);
+            if (b > a) HIP_TRY(hipMemcpyAsync((char*)c->hostStaging + a, (const char*)c->imageSum + a, b - a, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(c->hostPartDone[k], st));
+        }
+    }
     HIP_TRY(hipEventRecord(c->hostCopyDone, st));
     c->hostCopyPending = true;
     return PT_OK;
@@ -1643,8 +1663,15 @@ int pt_host_image_wait(PtContext* c)
     if (!c) { pt_set_error("pt_host_image_wait: null context"); return PT_EINVAL; }
     if (!c->hostImage || !c->hostCopyPending) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->hostCopyDone));
-    if (!c->hostRegistered) memcpy(c->hostImage, c->hostStaging, (size_t)c->numPixels * 3 * sizeof(float));
+    if (c->hostRegistered) HIP_TRY(hipEventSynchronize(c->hostCopyDone));
+    else {
+        const size_t bytes = (size_t)c->numPixels * 3 * sizeof(float);
+        for (int k = 0; k < PtContext::kHostCopyParts; ++k) {
+            const size_t a = hostPartStart(bytes, k), b = hostPartStart(bytes, k + 1);
+            HIP_TRY(hipEventSynchronize(c->hostPartDone[k]));
+            memcpy((char*)c->hostImage + a, (const char*)c->hostStaging + a, b - a);
+        }
+    }
     c->hostCopyPending = false;
     return PT_OK;
 }

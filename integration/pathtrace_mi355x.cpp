@@ -110,12 +110,12 @@ void pathtraceInit(Scene* scene)
     if (pt_create(&d, /* device */ 0, &ctx) != PT_OK) die("pathtraceInit");
     if (pt_set_option(ctx, PT_OPT_MATERIAL_SORT, MATERIAL_SORTING) != PT_OK) die("pathtraceInit");
     /* runCuda calls pathtrace(pbo, 0, ++iteration) once per frame (src/main.cpp:812-837).  The iterations behind the one
-     * asked for are rendered ahead in the same launch group, 64 at a time (PT_LOOKAHEAD), and handed out one per call:
+     * asked for are rendered ahead in the same launch group, 128 at a time (PT_LOOKAHEAD), and handed out one per call:
      * two halves of the path-state rows take turns, so rows for twice as many iterations are allocated, fewer when the
      * device cannot hold them.  One stream per launch group, so that no call waits inside the library. */
     const char* aheadEnv = getenv("PT_LOOKAHEAD");
     lookahead = 0;
-    for (int a = aheadEnv ? atoi(aheadEnv) : 64; a >= 2; a /= 2)
+    for (int a = aheadEnv ? atoi(aheadEnv) : 128; a >= 2; a /= 2)
         if (pt_set_option(ctx, PT_OPT_BATCH, 2 * (a > 256 ? 256 : a)) == PT_OK) { lookahead = a > 256 ? 256 : a; break; }
     if (pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, 1) != PT_OK) die("pathtraceInit");
     /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): its memory is

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """pathtrace() calls per second through the file a maintainer of the reference adds (integration/pathtrace_mi355x.cpp).
 
-    python tools/shim_rate.py [--workload dragon] [--calls 257] [--res 1920 1080] [--lookahead 64]
+    python tools/shim_rate.py [--workload dragon] [--calls 513] [--res 1920 1080] [--lookahead 128]
 
 oracle/_ref/ref_render is the reference's own scene loader (its scene.cpp, compiled where it lies) in front of that
 file and of libmi_pathtrace.so, with a headless main that calls pathtrace(nullptr, 0, iteration) once per iteration and
@@ -29,9 +29,9 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="dragon")
-    ap.add_argument("--calls", type=int, default=257)
+    ap.add_argument("--calls", type=int, default=513)
     ap.add_argument("--res", type=int, nargs=2, default=[1920, 1080])
-    ap.add_argument("--lookahead", type=int, default=64)
+    ap.add_argument("--lookahead", type=int, default=128)
     ap.add_argument("--keep", help="directory to write the exported scene into (default: a temporary one)")
     a = ap.parse_args()
     import conftest
