@@ -41,7 +41,9 @@ def nice(kernel):
 def load(root):
     """{kernel: {dispatch id: {counter: value, '_ns': duration}}}"""
     d = defaultdict(lambda: defaultdict(dict))
-    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    # one run per pass: gpurun merges the files of every run into the same local directory, so only the newest counts
+    files = sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             k = nice(r["Kernel_Name"])
             if not k:
