@@ -204,11 +204,11 @@ def main():
             torch.cuda.synchronize()
 
     # iterations per launch group: every kernel launch ends with the few longest rays of its bounce, a cost per launch
-    # and not per iteration, so groups are as large as 210 GB of path state (about 195 B per pixel and iteration) allow,
+    # and not per iteration, so groups are as large as 220 GB of path state (203 B per pixel and iteration) allow,
     # in powers of two so that the persistent traversal grid divides evenly over the rows
-    budget = min(210e9, 0.8 * torch.cuda.mem_get_info()[0])       # never more than four fifths of what is free now
+    budget = min(220e9, 0.8 * torch.cuda.mem_get_info()[0])       # never more than four fifths of what is free now
     per_step = per_rank_iterations(args.scaling, world, args.spp_per_step, args.total_spp)
-    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 195.0 * b <= budget)
+    B = args.spp_per_step if args.spp_per_step > 0 else next(b for b in (512, 256, 128, 64, 32, 16, 8) if b == 8 or npix * 203.0 * b <= budget)
     if args.scaling == "strong":
         B = min(B, per_step)
     B = max(1, min(B, 512))
@@ -445,7 +445,7 @@ def main():
                                         "ms_per_call_host_copy_queued": round((f3 - f2) / n_calls * 1e3, 4),
                                         "first_call_ms": round((f1 - f0) * 1e3, 2), "calls": n_calls, "iterations_rendered_ahead": ahead,
                                         "host_copy_bytes_per_call": int(npix * 12), "host_image_equals_device_sum": ok,
-                                        "path_state_bytes": int(195 * npix) * 2 * ahead,
+                                        "path_state_bytes": int(203 * npix) * 2 * ahead,
                                         "how": "pt_trace_lookahead(iteration, ahead) + pt_host_image_wait once per sample per pixel: the call sequence of "
                                                "pathtrace(pbo = NULL, frame, iteration) in integration/pathtrace_mi355x.cpp, device-to-host copy of the running "
                                                "sum (W*H*12 bytes) included; the first call renders a whole group before it returns"}

@@ -337,14 +337,15 @@ PT_DEV float hitTriangleRec(float4 a, float4 b, float4 c, F3 lo, F3 ld, F3& bary
  * box passes every ancestor.  The leaf boxes therefore are a FILTER on triangle hits, and the
  * hierarchy that is walked to find those hits is free.  This traversal walks its own: 4-wide
  * nodes down to boxes around one or two triangles, nearest child first, entry distance kept on
- * the stack for pruning at pop time, boxes that only have to be conservative (kBoxSlack).  A
- * closest hit is checked against the box of its leaf in the reference's BVH, with the
- * reference's arithmetic (passesHostLeafBox), and the reference's choice among equals is
- * reproduced with a per-triangle visit rank computed on the host from the reference's order.
- * (The reference also skips a node whose entry distance exceeds the closest hit so far.  For
- * boxes that contain their triangles that can only skip triangles that would lose anyway —
- * up to rounding at a box face, where its result depends on its visiting order; this
- * traversal then returns the closest hit that passes its leaf box.)
+ * the stack for pruning at pop time, boxes that only have to be conservative (kBoxSlack), and the
+ * reference's choice among equals reproduced with a per-triangle visit rank computed on the
+ * host from the reference's order.  The reference also skips a node whose entry distance
+ * exceeds the closest hit so far.  For boxes that contain their triangles that can only skip
+ * triangles that would lose anyway — up to rounding at a box face, where its result depends on
+ * its visiting order.  The walk therefore also keeps the runner-up distance, the finished walk's
+ * winner is checked against the box of its leaf in the reference's BVH with the reference's
+ * arithmetic (travCertain), and the rare ray for which that check does not settle the matter is
+ * walked again in the reference's own order over the reference's own nodes (travReference).
  *
  * stack: this lane's column of a [kStackDepth][kBlock] LDS array (refs in rows 0..kLdsStack-1,
  * entry distances in the rows above); deeper entries spill to private memory.
@@ -366,7 +367,7 @@ PT_DEV void travInit(const DGeom& g, const Ray& r, MeshTrav& tv)
     tv.ld = normalize(mulMV(g.I, r.d, 0.0f));
     /* reciprocal for the walked boxes only, which carry a slack of 2^-15: the hardware's one-ulp approximation (one
      * instruction per component instead of an IEEE division) is far inside it; the check of a hit against its host
-     * leaf box takes the true quotient (passesHostLeafBox) */
+     * leaf box takes the true quotient (refSlab) */
     tv.invDir = f3(__builtin_amdgcn_rcpf(tv.ld.x), __builtin_amdgcn_rcpf(tv.ld.y), __builtin_amdgcn_rcpf(tv.ld.z));
     tv.closestT = 3.402823466e+38f;
     tv.best = -1;
