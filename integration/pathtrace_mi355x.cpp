@@ -117,7 +117,11 @@ void pathtraceInit(Scene* scene)
     lookahead = 0;
     for (int a = aheadEnv ? atoi(aheadEnv) : 128; a >= 2; a /= 2)
         if (pt_set_option(ctx, PT_OPT_BATCH, 2 * (a > 256 ? 256 : a)) == PT_OK) { lookahead = a > 256 ? 256 : a; break; }
-    if (pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, 1) != PT_OK) die("pathtraceInit");
+    /* one stream per launch group, fixed, so that no call waits inside the library for a measurement of launch shapes
+     * (three streams measured slower behind the serve stream and the host copies: 1.32 against 1.10 ms per call;
+     * PT_LOOKAHEAD_STREAMS sets another number) */
+    const char* streamsEnv = getenv("PT_LOOKAHEAD_STREAMS");
+    if (pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, streamsEnv ? atoi(streamsEnv) : 1) != PT_OK) die("pathtraceInit");
     /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): its memory is
      * page-locked where it lies, so the copy runs asynchronously at the bus rate */
     if (pt_bind_host_image(ctx, reinterpret_cast<float*>(scene->state.image.data())) != PT_OK) die("pathtraceInit");

@@ -66,6 +66,23 @@ int main(int argc, char** argv)
     cameraPosition += cam.lookAt;
     cam.position = cameraPosition;
 
+    if (getenv("REF_RENDER_PIN_MATERIALS")) {
+        /* The loader's loadGLTFMaterial fills a `Material mat;` it never zeroes (src/scene.cpp:96): index of refraction, the
+         * specular block and the subsurface fields of a glTF material are whatever the stack held.  For timing runs that
+         * have to be comparable, a material whose subsurface switch is neither 0 nor 1, or whose index of refraction is no
+         * plausible number, gets those fields set (no subsurface, 1.5), as this repository's own loader sets them. */
+        int pinned = 0;
+        for (Material& m : scene->materials) {
+            const bool wild = (m.subsurfaceEnabled != 0 && m.subsurfaceEnabled != 1) || !(m.indexOfRefraction >= 1.0f && m.indexOfRefraction <= 4.0f);
+            if (!wild) continue;
+            m.specular.exponent = 0.0f; m.specular.color = glm::vec3(0.0f);
+            m.subsurfaceColor = glm::vec3(0.0f); m.subsurfaceRadius = 0.0f; m.subsurfaceRadiusRGB = glm::vec3(0.0f);
+            m.subsurfaceScale = 0.0f; m.subsurfaceAnisotropy = 0.0f; m.subsurfaceEnabled = 0;
+            m.indexOfRefraction = 1.5f;
+            ++pinned;
+        }
+        fprintf(stderr, "ref_render: %d materials had uninitialised fields pinned\n", pinned);
+    }
     {
         uint64_t hm = fnv(scene->materials.data(), scene->materials.size() * sizeof(Material));
         uint64_t hg = fnv(scene->geoms.data(), scene->geoms.size() * sizeof(Geom));

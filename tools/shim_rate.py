@@ -91,6 +91,9 @@ def main():
         env.pop("LD_BIND_NOW", None)
         env["PT_LOOKAHEAD"] = str(a.lookahead)
         env["PT_HOST_COPY"] = mode
+        env["REF_RENDER_PIN_MATERIALS"] = "1"
+        if os.environ.get("SHIM_STREAMS"):
+            env["PT_LOOKAHEAD_STREAMS"] = os.environ["SHIM_STREAMS"]
         r = subprocess.run([render, path, str(a.calls), os.path.join(out, "sum.bin"), str(a.res[0]), str(a.res[1])],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
         err = r.stderr.decode(errors="replace")
