@@ -143,6 +143,7 @@ def _load():
         "pt_last_error": (C.c_char_p, []),
         "pt_version": (C.c_char_p, []),
         "pt_resource_calls": (C.c_ulonglong, []),
+        "pt_set_tree_passes": (C.c_int, [C.c_int]),
         "pt_bvh_build": (ip, [vp, ip, ip, C.POINTER(vp)]),
         "pt_bvh_nodes": (vp, [vp, C.POINTER(ip)]),
         "pt_bvh_indices": (vp, [vp, C.POINTER(ip)]),
@@ -232,6 +233,11 @@ def bvh_device_layout(tris, max_depth=24):
         return st
     finally:
         lib.pt_bvh_free(h)
+
+
+def set_tree_passes(passes):
+    """Rounds of the walked tree's reinsertion optimiser for trees built from now on (0: none; default 3)."""
+    _check(lib.pt_set_tree_passes(int(passes)), "pt_set_tree_passes")
 
 
 def decode_png(data):

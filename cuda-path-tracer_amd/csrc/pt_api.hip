@@ -310,6 +310,9 @@ float geomArea(const PtGeom& g)
     return 1.0f;
 }
 
+/* passes of the walked tree's reinsertion optimiser (pt_set_tree_passes); PT_UPPER_OPT sets the start value */
+static std::atomic<int> g_treePasses{[] { const char* e = getenv("PT_UPPER_OPT"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : v > 16 ? 16 : v; }()};
+
 /* luminance * sin(theta) tables: conditional CDF per row, marginal CDF over rows
  * (buildEnvMapDistribution, src/pathtrace.cu:336-425; host arithmetic, libm sinf) */
 void buildEnvCdfs(const PtEnvMap& env, std::vector<float>& marginal, std::vector<float>& conditional, float& totalPower)
@@ -859,7 +862,7 @@ int flattenMesh(const PtTriangle* tris, int ntri, const PtBvhNode* nodes, int nn
                 done = true;
             } else if (U.leaves.size() >= 2) {
                 int root = U.build(0, (int)U.leaves.size(), 0);
-                static const int optPasses = [] { const char* e = getenv("PT_UPPER_OPT"); return e ? atoi(e) : 3; }();
+                const int optPasses = g_treePasses.load();
                 if (optPasses > 0 && U.leaves.size() >= 8) {
                     UpperOptimizer O(U, root);
                     const float before = getenv("PT_DEBUG_TAIL") ? O.cost() : 0.0f;
@@ -1904,6 +1907,13 @@ int pt_reset_stats(PtContext* c)
 void* pt_stream(PtContext* c) { return c ? (void*)c->stream : nullptr; }
 
 unsigned long long pt_resource_calls(void) { return g_resourceCalls.load(); }
+
+int pt_set_tree_passes(int passes)
+{
+    if (passes < 0 || passes > 16) { pt_set_error("pt_set_tree_passes: %d passes (0 to 16)", passes); return PT_EINVAL; }
+    g_treePasses.store(passes);
+    return PT_OK;
+}
 
 int pt_device_count(void)
 {

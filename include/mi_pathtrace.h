@@ -382,6 +382,14 @@ typedef struct PtLayoutStats {
 } PtLayoutStats;
 int pt_bvh_device_layout(const PtTriangle* triangles, int triangleCount, const PtBvh* bvh, PtLayoutStats* out);
 
+/* Set-up time against traversal speed.  The hierarchy the kernels walk is built by pt_create (and by
+ * pt_bvh_device_layout) on one host thread: a binned-SAH build over single triangles, then `passes` rounds in which
+ * subtrees are taken out and put back where they add the least surface area.  The default of 3 rounds is worth about
+ * 4 % of traversal time and most of the set-up time of a large mesh (10 s of 10.2 s for 3 M triangles); 0 skips them.
+ * Process-wide, read when a tree is built; results do not depend on it (the reference's own BVH, which decides the
+ * hits, is built separately: BVH::build, src/bvh.cpp:74-238).  No counterpart in the reference. */
+int pt_set_tree_passes(int passes);
+
 /* Guide buffers and denoising (role of captureNormalsAndAlbedo, src/pathtrace.cu:94-135, and of the denoiser
  * step of pathtrace(), :2885-2910).
  * pt_capture_gbuffer: the camera rays of iteration iter through the intersect stage; per pixel the normalised

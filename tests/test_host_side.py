@@ -180,6 +180,24 @@ def test_device_bvh_layout_is_valid_and_tighter_than_the_host_topology(pt, scene
         assert st.sahCostDevice <= st.sahCostHost * 1.05 + 1.0
 
 
+def test_tree_passes_setting_trades_set_up_for_area_only(pt, scenes):
+    """pt_set_tree_passes: the reinsertion rounds of the walked tree lower its summed node area and change nothing else
+    about a valid layout (every triangle referenced once); out-of-range values are refused."""
+    tris = scenes.blob_mesh(64, 65, 3, ((0, 0, 0), (0, 0, 0), (1, 1, 1)), [0, 1], bumps=8, amplitude=0.4)
+    try:
+        pt.set_tree_passes(0)
+        plain = pt.bvh_device_layout(tris)
+        pt.set_tree_passes(3)
+        opt = pt.bvh_device_layout(tris)
+    finally:
+        pt.set_tree_passes(3)
+    assert plain.trianglesReferenced == opt.trianglesReferenced == len(tris)
+    assert opt.sahCostDevice < plain.sahCostDevice
+    for bad in (-1, 17):
+        with pytest.raises(pt.PtError):
+            pt.set_tree_passes(bad)
+
+
 def test_det_math_close_to_libm(orc):
     rng = np.random.RandomState(0)
     cases = [("sin", rng.uniform(-7, 7, 20000)), ("cos", rng.uniform(-7, 7, 20000)), ("acos", rng.uniform(-1, 1, 20000)),
