@@ -144,6 +144,8 @@ def _load():
         "pt_version": (C.c_char_p, []),
         "pt_resource_calls": (C.c_ulonglong, []),
         "pt_set_tree_passes": (C.c_int, [C.c_int]),
+        "pt_set_camera": (C.c_int, [C.c_void_p, C.c_void_p]),
+        "pt_scene_fingerprint": (C.c_ulonglong, [C.c_void_p]),
         "pt_bvh_build": (ip, [vp, ip, ip, C.POINTER(vp)]),
         "pt_bvh_nodes": (vp, [vp, C.POINTER(ip)]),
         "pt_bvh_indices": (vp, [vp, C.POINTER(ip)]),
@@ -233,6 +235,11 @@ def bvh_device_layout(tris, max_depth=24):
         return st
     finally:
         lib.pt_bvh_free(h)
+
+
+def scene_fingerprint(desc):
+    """pt_scene_fingerprint of a PtSceneDesc pointer (Scene.desc): equal for descriptions that differ in the camera's pose only."""
+    return int(lib.pt_scene_fingerprint(desc))
 
 
 def set_tree_passes(passes):
@@ -438,6 +445,10 @@ class Tracer:
 
     def clear(self):
         _check(lib.pt_clear(self._h), "pt_clear")
+
+    def set_camera(self, camera):
+        """A new camera (PtCamera, same resolution) for the iterations traced from now on; the sum is not cleared."""
+        _check(lib.pt_set_camera(self._h, C.byref(camera)), "pt_set_camera")
 
     def set_option(self, opt, value):
         _check(lib.pt_set_option(self._h, int(opt), int(value)), "pt_set_option")

@@ -36,8 +36,8 @@ static bool endsWith(const std::string& s, const char* suf)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch] [--denoise] [--gpus G]\n", argv[0]); return 2; }
-    int iterations = -1, W = 0, H = 0, depth = 0, gpus = 1;
+    if (argc < 2) { fprintf(stderr, "usage: %s scene.json [-n iterations] [-r W H] [-d depth] [-o out.png|.hdr|.ppm|.pfm] [--batch] [--denoise] [--gpus G] [--restart-after K]\n", argv[0]); return 2; }
+    int iterations = -1, W = 0, H = 0, depth = 0, gpus = 1, restartAfter = 0;
     bool batch = false, denoise = false;
     std::string out;
     for (int i = 2; i < argc; ++i) {
@@ -48,6 +48,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--batch")) batch = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--denoise")) denoise = true;
+        else if (!strcmp(argv[i], "--restart-after") && i + 1 < argc) restartAfter = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     Scene* scene = nullptr;
@@ -91,6 +92,15 @@ int main(int argc, char** argv)
     } else {
         pathtraceFree();                 /* the reference frees before the first init as well (src/main.cpp:814) */
         pathtraceInit(scene);
+        if (restartAfter > 0) {
+            /* what the reference's preview does when the camera has moved (src/main.cpp:812-822), without the move: K calls,
+             * then iteration back to zero, pathtraceFree(), pathtraceInit() — the render that follows starts from nothing */
+            for (int it = 1; it <= restartAfter; ++it) pathtrace(nullptr, 0, it);
+            const unsigned long long before = pt_resource_calls();
+            pathtraceFree();
+            pathtraceInit(scene);
+            fprintf(stderr, "restart after %d calls: %llu device resources created or released\n", restartAfter, pt_resource_calls() - before);
+        }
         if (batch) {
             pathtraceRange(1, iterations);
         } else {
@@ -143,7 +153,7 @@ int main(int argc, char** argv)
     if (rc != PT_OK) { fprintf(stderr, "%s\n", pt_last_error()); return 1; }
     printf("%s: %d iterations, %dx%d, traced depth %d, %d context(s) -> %s\n", argv[1], iterations, w, h, gui.TracedDepth, gpus, out.c_str());
     for (PtContext* c : split) pt_destroy(c);
-    pathtraceFree();
+    pathtraceRelease();
     pt_scene_free(scene);
     return 0;
 }

@@ -28,12 +28,18 @@ struct GuiDataContainer { int TracedDepth = 0; };   /* src/utilities.h / src/mai
 
 void InitDataContainer(GuiDataContainer* guiData);
 void pathtraceInit(Scene* scene);
+/* Releases the caller's side (the host image is unbound, the device is idle) but keeps the context parked: the next
+ * pathtraceInit() with a scene that differs in the camera's pose only — what the reference's preview does on every camera
+ * move, src/main.cpp:812-822 — takes it back without rebuilding anything.  pathtraceRelease() frees the device memory too. */
 void pathtraceFree();
+void pathtraceRelease();
 /* pbo: DEVICE pointer to W*H uchar4 or nullptr (headless); frame is unused as in the reference
  * (src/main.cpp:825-826).  After the call the scene's host image holds the running sum.
  * The reference's loop calls this once per frame with iteration = 1, 2, 3, ...: the iterations behind the one asked
  * for are rendered ahead in the same launch group (pathtraceSetLookahead) and every later call only adds its own, so
- * the image after call k is bit for bit the sum of iterations 1..k while the device works at the rate of launch groups. */
+ * the image after call k is bit for bit the sum of iterations 1..k while the device works at the rate of launch groups.
+ * The first groups after an initialisation are small (8, 8, 8, 16, 16, 32, ... iterations) so that the first frames after a
+ * camera move arrive in milliseconds; the full depth is reached after about 250 calls. */
 void pathtrace(uchar4* pbo, int frame, int iteration);
 
 /* additions for headless use */
@@ -45,7 +51,7 @@ void pathtraceSetMaterialSorting(int on);
 void pathtraceSetHostCopy(int mode);
 void pathtraceHostImageWait();
 /* iterations rendered ahead of the calls (default 128, environment PT_LOOKAHEAD; 0 or 1: one iteration per call).  Path
- * state for twice as many iterations is allocated, about 195 bytes per pixel each. */
+ * state for twice as many iterations is allocated, 203 bytes per pixel each. */
 void pathtraceSetLookahead(int iterations);
 void pathtraceRange(int firstIteration, int lastIterationInclusive);    /* batched iterations, then one host copy */
 PtContext* pathtraceContext();

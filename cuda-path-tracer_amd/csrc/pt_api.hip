@@ -1728,7 +1728,7 @@ int pt_trace_lookahead(PtContext* c, int iter, int ahead, int iter_last)
     /* keep the device rendering: the group after this one goes onto the other half of the rows, whose contributions
      * have all joined the sum (the main stream waited for each of them) */
     if (!next.valid) {
-        int rc = launch(next, cur.base + cur.count, cur.rowBase == 0 ? B : 0);
+        int rc = launch(next, cur.base + cur.count, cur.rowBase == 0 ? c->batch / 2 : 0);       /* the halves are fixed, so `ahead` may differ from call to call */
         if (rc != PT_OK) return rc;
     }
     if (c->aheadServed == 0) HIP_TRY(hipStreamWaitEvent(c->serveStream, cur.done, 0));
@@ -1815,6 +1815,68 @@ int pt_clear(PtContext* c)
     HIP_TRY(hipMemsetAsync(c->imageSum, 0, (size_t)c->numPixels * 3 * sizeof(float), c->stream));
     c->sumTouchedOnMain = true;
     return PT_OK;
+}
+
+int pt_set_camera(PtContext* c, const PtCamera* cam)
+{
+    if (!c || !cam) { pt_set_error("pt_set_camera: null argument"); return PT_EINVAL; }
+    if (cam->resolution[0] != c->cam.resolution[0] || cam->resolution[1] != c->cam.resolution[1]) {
+        pt_set_error("pt_set_camera: resolution %d x %d, the context was created for %d x %d", cam->resolution[0], cam->resolution[1], c->cam.resolution[0], c->cam.resolution[1]);
+        return PT_EINVAL;
+    }
+    /* launches take the camera by value, so work already queued keeps the old one; rows rendered ahead were made with it */
+    c->aheadCur.valid = false; c->aheadNext.valid = false;
+    c->cam = *cam;
+    return PT_OK;
+}
+
+/* 64-bit FNV-1a over 8-byte words (the tail byte-wise), continued from h */
+static uint64_t hashBytes(const void* p, size_t n, uint64_t h)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; }
+    for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+/* an array of `count` records: all of it up to 32 MB, beyond that 65 536 records spread evenly plus the first and last */
+static uint64_t hashArray(const void* p, size_t count, size_t stride, uint64_t h)
+{
+    h = hashBytes(&count, sizeof(count), h);
+    if (!p || count == 0) return h;
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    if (count * stride <= (32u << 20)) return hashBytes(b, count * stride, h);
+    const size_t samples = 65536;
+    for (size_t k = 0; k < samples; ++k) h = hashBytes(b + (count - 1) * k / (samples - 1) * stride, stride, h);
+    return h;
+}
+
+unsigned long long pt_scene_fingerprint(const PtSceneDesc* d)
+{
+    if (!d) return 0;
+    uint64_t h = 1469598103934665603ull;
+    h = hashArray(d->geoms, (size_t)d->geomCount, sizeof(PtGeom), h);
+    h = hashArray(d->materials, (size_t)d->materialCount, sizeof(PtMaterial), h);
+    h = hashBytes(&d->meshCount, sizeof(d->meshCount), h);
+    for (int m = 0; m < d->meshCount; ++m) {
+        const PtMesh& mesh = d->meshes[m];
+        h = hashArray(mesh.triangles, (size_t)mesh.triangleCount, sizeof(PtTriangle), h);
+        h = hashArray(mesh.nodes, (size_t)(mesh.nodes ? mesh.nodeCount : 0), sizeof(PtBvhNode), h);
+        h = hashArray(mesh.triangleIndices, (size_t)(mesh.triangleIndices ? mesh.triangleIndexCount : 0), sizeof(int32_t), h);
+    }
+    h = hashBytes(&d->textureCount, sizeof(d->textureCount), h);
+    for (int t = 0; t < d->textureCount; ++t) {
+        const PtTexture& tx = d->textures[t];
+        const int32_t dims[3] = { tx.width, tx.height, tx.components };
+        h = hashBytes(dims, sizeof(dims), h);
+        h = hashArray(tx.data, tx.data && tx.width > 0 && tx.height > 0 ? (size_t)tx.width * tx.height : 0, (size_t)(tx.components > 0 ? tx.components : 1), h);
+    }
+    const int32_t env[3] = { d->env.enabled && d->env.data ? 1 : 0, d->env.width, d->env.height };
+    h = hashBytes(env, sizeof(env), h);
+    if (env[0]) h = hashArray(d->env.data, (size_t)d->env.width * d->env.height, 3 * sizeof(float), h);
+    h = hashBytes(d->camera.resolution, sizeof(d->camera.resolution), h);
+    h = hashBytes(&d->traceDepth, sizeof(d->traceDepth), h);
+    return h ? h : 1;
 }
 
 int pt_set_option(PtContext* c, int option, int value)

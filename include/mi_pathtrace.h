@@ -309,6 +309,16 @@ int pt_bind_image(PtContext* ctx, float* dev_rgb);
 /* Load a running sum (checkpoint/resume: the image is a plain sum). */
 int pt_upload_image(PtContext* ctx, const float* host_rgb);
 int pt_clear(PtContext* ctx);
+/* A new camera for the iterations traced from now on, everything else of the scene kept: the reference's preview calls
+ * pathtraceFree() + pathtraceInit() whenever the camera moves (src/main.cpp:812-822), which there is a few allocations
+ * and copies, and here would rebuild the hierarchy the kernels walk (seconds for a large mesh).  Same resolution
+ * only (PT_EINVAL otherwise); does not clear the running sum (pt_clear does); iterations rendered ahead are dropped. */
+int pt_set_camera(PtContext* ctx, const PtCamera* camera);
+/* A hash of everything in a scene description that pt_create builds device data from — geoms, materials, triangles and
+ * host BVHs (arrays beyond 32 MB by 65 536 evenly spread records), textures, environment map, resolution, trace depth —
+ * and not of the camera's pose: two descriptions with one fingerprint can share a context through pt_set_camera.
+ * Never 0 for a description; 0 for NULL. */
+unsigned long long pt_scene_fingerprint(const PtSceneDesc* scene);
 int pt_sync(PtContext* ctx);
 int pt_set_option(PtContext* ctx, int option, int value);
 int pt_stats(PtContext* ctx, PtStats* out);

@@ -21,6 +21,12 @@ static_assert(sizeof(Material) == sizeof(PtMaterial) && sizeof(Triangle) == size
               "the reference's PODs and the C ABI's must have one layout");
 
 static PtContext* ctx = nullptr;
+/* runCuda frees and initialises again whenever the camera moves (src/main.cpp:812-822).  Building the device scene takes
+ * seconds for a large mesh, so pathtraceFree() parks the context, and a pathtraceInit() whose scene differs from the
+ * parked one in the camera's pose only takes it back (pt_set_camera + pt_clear).  Another scene destroys the parked
+ * context first; PT_KEEP_CONTEXT=0 makes pathtraceFree() free at once, as the reference does. */
+static PtContext* parked = nullptr;
+static unsigned long long parkedFingerprint = 0;
 static Scene* hst_scene = nullptr;
 static GuiDataContainer* guiData = nullptr;
 static int lookahead = 0;               /* iterations rendered ahead of the calls (0: one per call) */
@@ -37,8 +43,22 @@ void InitDataContainer(GuiDataContainer* g) { guiData = g; }
 
 void pathtraceFree()
 {
-    if (ctx) pt_destroy(ctx);
+    static const bool keep = [] { const char* e = getenv("PT_KEEP_CONTEXT"); return !(e && atoi(e) == 0); }();
+    if (ctx && keep) {
+        if (parked) pt_destroy(parked);
+        if (pt_bind_host_image(ctx, nullptr) != PT_OK) die("pathtraceFree");      /* waits for the device; the scene's image memory is its own again */
+        parked = ctx;
+    } else if (ctx) pt_destroy(ctx);
     ctx = nullptr;
+}
+
+/* iterations to render ahead when call `iter` needs a new launch group: 8, 8, 8, 16, 16, 32, 32, ... up to `most`, so that
+ * the first frames after an initialisation (a camera move) arrive in milliseconds */
+static int aheadFor(int iter, int most)
+{
+    int a = 8;
+    while (2 * a <= iter && 2 * a <= most) a *= 2;
+    return a < most ? a : most;
 }
 
 void pathtraceInit(Scene* scene)
@@ -107,21 +127,31 @@ void pathtraceInit(Scene* scene)
     memcpy(&d.camera, &scene->state.camera, sizeof(PtCamera));
     d.traceDepth = scene->state.traceDepth;
     d.iterations = (int32_t)scene->state.iterations;
-    if (pt_create(&d, /* device */ 0, &ctx) != PT_OK) die("pathtraceInit");
+    const unsigned long long fingerprint = pt_scene_fingerprint(&d);
+    if (parked && fingerprint == parkedFingerprint && pt_set_camera(parked, &d.camera) == PT_OK) {
+        /* the same scene from another place: the context is kept, the image starts from zero (src/pathtrace.cu:447) */
+        ctx = parked;
+        parked = nullptr;
+        if (pt_clear(ctx) != PT_OK) die("pathtraceInit");
+    } else {
+        if (parked) { pt_destroy(parked); parked = nullptr; }
+        if (pt_create(&d, /* device */ 0, &ctx) != PT_OK) die("pathtraceInit");
+        /* runCuda calls pathtrace(pbo, 0, ++iteration) once per frame (src/main.cpp:812-837).  The iterations behind the one
+         * asked for are rendered ahead in the same launch group, up to 128 at a time (PT_LOOKAHEAD), and handed out one per
+         * call: two halves of the path-state rows take turns, so rows for twice as many iterations are allocated, fewer
+         * when the device cannot hold them. */
+        const char* aheadEnv = getenv("PT_LOOKAHEAD");
+        lookahead = 0;
+        for (int a = aheadEnv ? atoi(aheadEnv) : 128; a >= 2; a /= 2)
+            if (pt_set_option(ctx, PT_OPT_BATCH, 2 * (a > 256 ? 256 : a)) == PT_OK) { lookahead = a > 256 ? 256 : a; break; }
+        /* one stream per launch group, fixed, so that no call waits inside the library for a measurement of launch shapes
+         * (three streams measured slower behind the serve stream and the host copies: 1.32 against 1.10 ms per call;
+         * PT_LOOKAHEAD_STREAMS sets another number) */
+        const char* streamsEnv = getenv("PT_LOOKAHEAD_STREAMS");
+        if (pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, streamsEnv ? atoi(streamsEnv) : 1) != PT_OK) die("pathtraceInit");
+    }
+    parkedFingerprint = fingerprint;
     if (pt_set_option(ctx, PT_OPT_MATERIAL_SORT, MATERIAL_SORTING) != PT_OK) die("pathtraceInit");
-    /* runCuda calls pathtrace(pbo, 0, ++iteration) once per frame (src/main.cpp:812-837).  The iterations behind the one
-     * asked for are rendered ahead in the same launch group, 128 at a time (PT_LOOKAHEAD), and handed out one per call:
-     * two halves of the path-state rows take turns, so rows for twice as many iterations are allocated, fewer when the
-     * device cannot hold them.  One stream per launch group, so that no call waits inside the library. */
-    const char* aheadEnv = getenv("PT_LOOKAHEAD");
-    lookahead = 0;
-    for (int a = aheadEnv ? atoi(aheadEnv) : 128; a >= 2; a /= 2)
-        if (pt_set_option(ctx, PT_OPT_BATCH, 2 * (a > 256 ? 256 : a)) == PT_OK) { lookahead = a > 256 ? 256 : a; break; }
-    /* one stream per launch group, fixed, so that no call waits inside the library for a measurement of launch shapes
-     * (three streams measured slower behind the serve stream and the host copies: 1.32 against 1.10 ms per call;
-     * PT_LOOKAHEAD_STREAMS sets another number) */
-    const char* streamsEnv = getenv("PT_LOOKAHEAD_STREAMS");
-    if (pt_set_option(ctx, PT_OPT_LAUNCH_STREAMS, streamsEnv ? atoi(streamsEnv) : 1) != PT_OK) die("pathtraceInit");
     /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): its memory is
      * page-locked where it lies, so the copy runs asynchronously at the bus rate */
     if (pt_bind_host_image(ctx, reinterpret_cast<float*>(scene->state.image.data())) != PT_OK) die("pathtraceInit");
@@ -141,7 +171,7 @@ void pathtrace(uchar4* pbo, int /* frame */, int iter)
     if (!ctx) { fprintf(stderr, "pathtrace: pathtraceInit has not been called\n"); exit(EXIT_FAILURE); }
     if (guiData) guiData->TracedDepth = hst_scene->state.traceDepth;        /* src/pathtrace.cu:2712-2715 */
     const int last = (int)hst_scene->state.iterations;                      /* the loop saves and exits there (src/main.cpp:831-837) */
-    if (pt_trace_lookahead(ctx, iter, lookahead > 0 ? lookahead : 1, iter <= last ? last : 0) != PT_OK) die("pathtrace");
+    if (pt_trace_lookahead(ctx, iter, lookahead > 0 ? aheadFor(iter, lookahead) : 1, iter <= last ? last : 0) != PT_OK) die("pathtrace");
     if (pbo && pt_display(ctx, iter, reinterpret_cast<uint8_t*>(pbo)) != PT_OK) die("pathtrace");      /* pbo: a device pointer, as the GL interop map yields */
     /* The running sum is back on the host when the call returns, as after the blocking copy at src/pathtrace.cu:2913-2917.
      * With PT_HOST_COPY=queued the copy of this call is only queued — it runs while the next call is being made, each copy

@@ -18,6 +18,7 @@
 
 struct uchar4;
 void pathtraceHostImageWait();      /* integration/pathtrace_mi355x.cpp */
+extern "C" unsigned long long pt_resource_calls(void);      /* include/mi_pathtrace.h */
 
 /* FNV-1a over a block of loader output: two runs that print different values were not given the same scene */
 static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
@@ -101,6 +102,7 @@ int main(int argc, char** argv)
      * carries the one-off set-up of the first launch groups) apart */
     double firstMs = 0.0;
     auto t0 = std::chrono::steady_clock::now();
+    auto tHalf = t0;
     for (int it = 1; it <= iterations; ++it) {
         pathtrace(nullptr, 0, it);
         if (it == 1) {
@@ -108,9 +110,30 @@ int main(int argc, char** argv)
             firstMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
             t0 = t1;
         }
+        if (it == iterations / 2) tHalf = std::chrono::steady_clock::now();
     }
+    const double lastHalfMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tHalf).count();
     pathtraceHostImageWait();
-    const double restMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    double restMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (const char* at = getenv("REF_RENDER_REINIT_AT")) {
+        /* what runCuda does when the camera has moved (src/main.cpp:812-822): iteration back to 0, pathtraceFree(),
+         * pathtraceInit() — here after the calls above, with the camera moved by REF_RENDER_MOVE="dx,dy,dz"; then
+         * atoi(REF_RENDER_REINIT_AT) calls from iteration 1 again, whose sum is what gets written */
+        float mv[3] = { 0.5f, 0.25f, 0.0f };
+        if (const char* m = getenv("REF_RENDER_MOVE")) sscanf(m, "%f,%f,%f", &mv[0], &mv[1], &mv[2]);
+        cam.position += glm::vec3(mv[0], mv[1], mv[2]);
+        const unsigned long long before = pt_resource_calls();
+        auto r0 = std::chrono::steady_clock::now();
+        pathtraceFree();
+        pathtraceInit(scene);
+        pathtrace(nullptr, 0, 1);
+        const double reinitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
+        fprintf(stderr, "ref_render: camera moved; pathtraceFree + pathtraceInit + first pathtrace() call %.3f ms, %llu device resources created or released\n",
+                reinitMs, pt_resource_calls() - before);
+        const int again = atoi(at);
+        for (int it = 2; it <= again; ++it) pathtrace(nullptr, 0, it);
+        pathtraceHostImageWait();
+    }
     const char* copyEnv = getenv("PT_HOST_COPY");
     const bool queued = copyEnv && std::string(copyEnv) == "queued";
     FILE* f = fopen(argv[3], "wb");
@@ -119,8 +142,9 @@ int main(int argc, char** argv)
     fwrite(wh, 4, 2, f);
     fwrite(scene->state.image.data(), 12, scene->state.image.size(), f);
     fclose(f);
-    fprintf(stderr, "ref_render: %d iterations at %dx%d, traced depth %d, first pathtrace() call %.3f ms, the other %d calls %.4f ms each (%s)\n",
+    fprintf(stderr, "ref_render: %d iterations at %dx%d, traced depth %d, first pathtrace() call %.3f ms, the other %d calls %.4f ms each, the last %d calls %.4f ms each (%s)\n",
             iterations, cam.resolution.x, cam.resolution.y, gui.TracedDepth, firstMs, iterations - 1, iterations > 1 ? restMs / (iterations - 1) : 0.0,
+            iterations - iterations / 2, iterations > 1 ? lastHalfMs / (iterations - iterations / 2) : 0.0,
             queued ? "host copies queued in call order, the last one waited for" : "host image up to date after every call");
     pathtraceFree();
     return 0;

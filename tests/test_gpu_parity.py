@@ -672,6 +672,20 @@ def test_pathtrace_surface_headless_driver(pt, scenes, orc, gpu_ok, tmp_path):
             got = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
         assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
         assert got.sum() > 0
+    # pathtraceFree() + pathtraceInit() in the middle of a render, as the reference's preview does when the camera moves:
+    # the parked context is taken back (a handful of resource calls instead of the hundreds of a pt_create), the render
+    # that follows starts from nothing; with PT_KEEP_CONTEXT=0 everything is freed and built again, same image
+    for keep in ("1", "0"):
+        out = str(tmp_path / ("restart%s.pfm" % keep))
+        r = subprocess.run([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", out, "--restart-after", "2"], timeout=120,
+                           stderr=subprocess.PIPE, env=dict(os.environ, PT_KEEP_CONTEXT=keep))
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        calls = int([l for l in r.stderr.decode().splitlines() if l.startswith("restart after")][-1].split(": ")[1].split()[0])
+        assert (calls < 16) if keep == "1" else (calls > 40), calls
+        with open(out, "rb") as f:
+            f.readline(); f.readline(); f.readline()
+            got = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
+        assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
     # the reference's own output forms: 8-bit PNG (averaged, x mirrored, clamped, truncated) and Radiance .hdr
     png, hdr = str(tmp_path / "img.png"), str(tmp_path / "img.hdr")
     subprocess.check_call([exe, path, "-n", str(n), "-r", str(W), str(H), "-d", "6", "-o", png], timeout=120)

@@ -180,6 +180,39 @@ def test_device_bvh_layout_is_valid_and_tighter_than_the_host_topology(pt, scene
         assert st.sahCostDevice <= st.sahCostHost * 1.05 + 1.0
 
 
+def test_scene_fingerprint_ignores_the_camera_pose_only(pt, scenes):
+    """pt_scene_fingerprint: equal for two descriptions that differ in where the camera is, different as soon as a
+    triangle, a material, a texture byte, the resolution or the trace depth differs (what decides whether the shims take a
+    parked context back on pathtraceInit)."""
+    def fp(edit=None, **kw):
+        sc = scenes.make_scene("dragon", res=kw.pop("res", (64, 48)), depth=kw.pop("depth", 8), grid=(20, 21), env_size=(32, 16), tex_size=8)
+        if edit:
+            edit(sc)
+        return pt.scene_fingerprint(sc.desc)
+
+    base = fp()
+    assert base != 0 and base == fp() and pt.scene_fingerprint(None) == 0
+
+    def move(sc):
+        cam = sc.desc.contents.camera
+        cam.position[0] += 1.5
+        cam.view[1] = 0.25
+
+    assert fp(move) == base
+    assert fp(res=(64, 40)) != base and fp(depth=7) != base
+
+    def recolour(sc):
+        sc.desc.contents.materials[1].color[0] = 0.123
+
+    def nudge(sc):
+        m = sc.desc.contents.meshes[0]
+        f = C.cast(m.triangles, C.POINTER(C.c_float))       # 25 floats per 100-byte triangle
+        f[5 * 25 + 4] += 1e-3
+
+    assert fp(recolour) != base and fp(nudge) != base
+    assert fp(lambda sc: sc.add_texture(np.zeros((4, 4, 3), np.uint8))) != base
+
+
 def test_tree_passes_setting_trades_set_up_for_area_only(pt, scenes):
     """pt_set_tree_passes: the reinsertion rounds of the walked tree lower its summed node area and change nothing else
     about a valid layout (every triangle referenced once); out-of-range values are refused."""
