@@ -406,6 +406,52 @@ def test_lookahead_calls_bit_exact(pt, scenes, orc, gpu_ok):
         tr.bind_host_image(None)
 
 
+def test_contexts_side_by_side_serve_lookahead_calls(pt, scenes, gpu_ok):
+    """Several contexts alive in one process, created at different moments (the second while the first still has
+    pipelined calls queued, a third after look-ahead work), serving look-ahead calls in turn with bound host images: each
+    image is the one-at-a-time render of its scene, bit for bit, and nothing waits for ever (every context owns a
+    high-priority stream; the runtime shares a process's few hardware queues among all streams)."""
+    kw = dict(res=(160, 96), depth=8, grid=(32, 33), env_size=(64, 32), tex_size=8)
+    sa, sb = scenes.make_scene("dragon", **kw), scenes.make_scene("chess", **kw)
+
+    def reference(sc, n):
+        t = pt.Tracer(sc)
+        for it in range(1, n + 1):
+            t.trace(it)
+        return t.image().copy()
+
+    ra, rb = reference(sa, 24), reference(sb, 24)
+    a = pt.Tracer(sa)
+    for it in range(1, 9):
+        a.trace(it)
+    b = pt.Tracer(sb)
+    ha, hb = np.zeros_like(ra), np.zeros_like(rb)
+    a.clear()
+    for t, h in ((a, ha), (b, hb)):
+        t.set_option(pt.PT_OPT_BATCH, 12)
+        t.set_option(pt.PT_OPT_LAUNCH_STREAMS, 1)
+        t.bind_host_image(h)
+    for it in range(1, 25):
+        a.trace_lookahead(it, 6, 24)
+        b.trace_lookahead(it, 6, 24)
+        if it % 3 == 0:
+            a.host_image_wait()
+            b.host_image_wait()
+    a.host_image_wait()
+    b.host_image_wait()
+    assert _same_bits(ha, ra) and _same_bits(hb, rb)
+    c = pt.Tracer(sa)
+    hc = np.zeros_like(ra)
+    c.set_option(pt.PT_OPT_BATCH, 12)
+    c.bind_host_image(hc)
+    for it in range(1, 25):
+        c.trace_lookahead(it, 6, 24)
+    c.host_image_wait()
+    assert _same_bits(hc, ra)
+    for t in (a, b, c):
+        t.bind_host_image(None)
+
+
 def o_path_bounces(pt, orc, sc, n):
     o = orc.Oracle(pt, sc, orc.MATH_DET)
     for it in range(1, n + 1):
