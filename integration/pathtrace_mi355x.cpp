@@ -152,8 +152,9 @@ void pathtraceInit(Scene* scene)
     }
     parkedFingerprint = fingerprint;
     if (pt_set_option(ctx, PT_OPT_MATERIAL_SORT, MATERIAL_SORTING) != PT_OK) die("pathtraceInit");
-    /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): its memory is
-     * page-locked where it lies, so the copy runs asynchronously at the bus rate */
+    /* hst_scene->state.image receives the running sum after every iteration (src/pathtrace.cu:2913-2917): the library
+     * page-locks its memory where it lies if the runtime allows that, and otherwise copies through a pinned buffer of its
+     * own in pieces; either way the copy is queued behind the call's addition to the sum */
     if (pt_bind_host_image(ctx, reinterpret_cast<float*>(scene->state.image.data())) != PT_OK) die("pathtraceInit");
     const char* copyEnv = getenv("PT_HOST_COPY");
     strictHostCopy = !(copyEnv && strcmp(copyEnv, "queued") == 0);
