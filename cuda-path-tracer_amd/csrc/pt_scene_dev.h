@@ -933,12 +933,16 @@ PT_DEV int lowerBound(const float* cdf, int size, float value)
 }
 
 /* lowerBound with a guide table.  For a CDF that never decreases (the host checks, and passes no guide otherwise) the
- * first entry >= value lies between the answers for the multiples of 1/64 on either side of value; guide[j] is the
- * answer for j/64 (64 entries of 16 bits = one 128-byte line per CDF), and value * 64 and j / 64 are exact in binary
- * floating point, so the bisection starts on a window of a few dozen entries — one or two lines of the CDF and five or
- * six dependent loads instead of the eleven, over six lines, that halving a 2 048-entry row takes.  Same index as
+ * first entry >= value lies between the answers for the multiples of 1/kCdfGuide on either side of value; guide[j] is
+ * the answer for j/kCdfGuide (16-bit entries), and value * kCdfGuide and j / kCdfGuide are exact in binary floating
+ * point, so the bisection starts on a window of a handful of entries — one line of the CDF and one to three dependent
+ * loads instead of the eleven, over six lines, that halving a 2 048-entry row takes.  (64 / 256 / 1 024 guide entries:
+ * the shade stage takes 0.170 / 0.166 / 0.164 ms per sample on the dragon-class workload.)  Same index as
  * lowerBound(cdf, size, value), including size - 1 when no entry qualifies. */
-constexpr int kCdfGuide = 64;
+#ifndef PT_CDF_GUIDE
+#define PT_CDF_GUIDE 1024
+#endif
+constexpr int kCdfGuide = PT_CDF_GUIDE;       /* a power of two */
 PT_DEV int lowerBoundGuided(const float* cdf, int size, const uint16_t* guide, float value)
 {
     if (!guide) return lowerBound(cdf, size, value);
