@@ -1318,7 +1318,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
         }
         TRY_RC(devUpload(c, &dMarg, marg.data(), marg.size()));
         TRY_RC(devUpload(c, &dCond, cond.data(), cond.size()));
-        /* guide tables of the CDF searches (lowerBoundGuided): the answers for the multiples of 1/64, for the marginal CDF and
+        /* guide tables of the CDF searches (lowerBoundGuided): the answers for the multiples of 1/kCdfGuide, for the marginal CDF and
          * for every row of the conditional one; only when no CDF starts below zero, ever decreases or holds a NaN, and indices fit 16 bits */
         const int W = d->env.width, H = d->env.height;
         auto monotone = [](const float* f, int n) { if (!(f[0] >= 0.0f)) return false; for (int i = 1; i < n; ++i) if (!(f[i] >= f[i - 1])) return false; return true; };
