@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <utility>
 #include <vector>
 
 #include <atomic>
@@ -1289,6 +1290,44 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     }
     DTexture* dTex;
     TRY_RC(devUpload(c, &dTex, tex.data(), tex.size()));
+    /* materials whose base-colour and metallic-roughness textures have one size get the two side by side, 8 bytes per texel in
+     * 4 x 4-texel tiles of 128 bytes (sampleTexturePair); pairs that several materials share are made once */
+    std::vector<DTexPair> pairs((size_t)d->materialCount);
+    DTexPair* dPairs = nullptr;
+    {
+        auto texel = [&](const PtTexture& pt, int x, int y) -> uint32_t {
+            const uint8_t* px = pt.data + ((size_t)y * pt.width + x) * pt.components;
+            if (pt.components == 1) return px[0] * 0x010101u | 0xff000000u;
+            if (pt.components == 3) return px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | 0xff000000u;
+            return px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | (uint32_t)px[3] << 24;
+        };
+        std::vector<std::pair<std::pair<int, int>, DTexPair>> made;
+        bool any = false;
+        for (int m = 0; m < d->materialCount; ++m) {
+            DTexPair& P = pairs[m];
+            P.data = nullptr; P.width = P.height = P.tilesPerRow = P.pad = 0;
+            const int b = d->materials[m].baseColorTextureIdx, r = d->materials[m].metallicRoughnessTextureIdx;
+            if (b < 0 || r < 0 || b >= d->textureCount || r >= d->textureCount) continue;
+            const PtTexture& tb = d->textures[b];
+            const PtTexture& tr = d->textures[r];
+            if (tb.width != tr.width || tb.height != tr.height || tb.components == 2 || tr.components == 2) continue;
+            bool found = false;
+            for (const auto& e : made) if (e.first == std::make_pair(b, r)) { P = e.second; found = true; break; }
+            if (!found) {
+                const int tilesX = (tb.width + 3) / 4, tilesY = (tb.height + 3) / 4;
+                std::vector<uint2> tiled((size_t)tilesX * tilesY * 16, make_uint2(0u, 0u));
+                for (int y = 0; y < tb.height; ++y)
+                    for (int x = 0; x < tb.width; ++x)
+                        tiled[((size_t)(y / 4) * tilesX + x / 4) * 16 + (size_t)(y % 4) * 4 + x % 4] = make_uint2(texel(tb, x, y), texel(tr, x, y));
+                uint2* dd;
+                TRY_RC(devUpload(c, &dd, tiled.data(), tiled.size()));
+                P.data = dd; P.width = tb.width; P.height = tb.height; P.tilesPerRow = tilesX;
+                made.push_back({ { b, r }, P });
+            }
+            any = true;
+        }
+        if (any) TRY_RC(devUpload(c, &dPairs, pairs.data(), pairs.size()));
+    }
 
     /* ---- lights (initializeLights, src/pathtrace.cu:232-267) */
     std::vector<DLight> lights;
@@ -1343,7 +1382,7 @@ int pt_create(const PtSceneDesc* d, int device, PtContext** out)
     SceneView& V = c->view;
     V.cameraOrigin = 0; V.leanHits = 0; V.traceDepth = c->traceDepth; memcpy(V.camPos, c->cam.position, sizeof(V.camPos));     /* set per call in traceBatch */
     V.geoms = dGeoms; V.materials = dMats; V.nodes = dNodes; V.triHot = dHot; V.triCold = dCold; V.triBox = dBox; V.leafOfOrig = dLeaf; V.hostNodes = dHostNodes; V.hostIndices = dHostIdx;
-    V.textures = dTex; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond; V.envGuide = dGuide;
+    V.textures = dTex; V.texPairs = dPairs; V.lights = dLights; V.envData = dEnv; V.envMarginal = dMarg; V.envConditional = dCond; V.envGuide = dGuide;
     V.numGeoms = d->geomCount; V.numMaterials = d->materialCount; V.numTextures = d->textureCount; V.numLights = (int)lights.size();
     V.envWidth = envOn ? d->env.width : 0; V.envHeight = envOn ? d->env.height : 0; V.envEnabled = envOn ? 1 : 0; V.useBvh = 1;
     V.envTotalPower = totalPower;

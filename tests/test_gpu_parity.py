@@ -196,7 +196,8 @@ def test_iterations_bit_exact_mesh_textures_env(pt, scenes, orc, gpu_ok):
 def test_ragged_texture_and_env_sizes_all_channel_counts(pt, scenes, orc, gpu_ok):
     """Textures whose sides are no multiple of the device tile (8 x 4 texels), with one, two, three and four channels, and
     environment maps whose width is no multiple of the column-search block (32) or smaller than one block: the device
-    layouts differ from the image files', the values fetched must not."""
+    layouts differ from the image files', the values fetched must not.  Materials whose two textures have one size are
+    sampled through the paired layout, the others one texture at a time."""
     rng = np.random.RandomState(5)
     for env_size, tex_sides in (((50, 23), ((13, 7), (9, 5), (1, 1), (33, 2))), ((97, 40), ((8, 4), (17, 31), (5, 64), (64, 3))),
                                 ((31, 16), ((2, 2), (7, 9), (16, 16), (3, 40)))):
@@ -205,7 +206,8 @@ def test_ragged_texture_and_env_sizes_all_channel_counts(pt, scenes, orc, gpu_ok
         for k, (comp, (w, h)) in enumerate(zip((1, 2, 3, 4), tex_sides)):
             img = rng.randint(0, 256, (h, w, comp)).astype(np.uint8)
             base = sc.add_texture(img[..., 0] if comp == 1 else img)
-            mr = sc.add_texture(rng.randint(0, 256, (h + 1, w + 2, 3)).astype(np.uint8))
+            # metallic-roughness of the base colour's size for two of the four (the device then keeps the pair side by side), of another size for the rest
+            mr = sc.add_texture(rng.randint(0, 256, (h, w, 3) if k % 2 == 0 else (h + 1, w + 2, 3)).astype(np.uint8))
             ids.append(sc.add_material(type=pt.PT_PBR, color=[0.9, 0.8, 0.7], roughness=0.6, metallic=0.5 * (k % 2), indexOfRefraction=1.5,
                                        baseColorTextureIdx=base, metallicRoughnessTextureIdx=mr))
         ident = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
